@@ -1,0 +1,44 @@
+# Build of the MI355X render path (libc2rt.so) and of the CPU oracle
+# (oracle/libc2rt_oracle.so, test infrastructure).  `make -j8`.
+#
+# Arithmetic flags are part of the contract: no contraction (the reference's
+# x86-64 code has separate mul/add), IEEE fp32 divide/sqrt, no fast-math.
+HIPCC      ?= hipcc
+CC         ?= gcc
+ARCH       ?= gfx950
+FPFLAGS    := -ffp-contract=off -fno-fast-math
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt \
+              -Wall -Wno-unused-function $(EXTRA_HIPFLAGS)
+CXXFLAGS   := -O2 -std=c++17 -fPIC $(FPFLAGS) -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
+CSRC       := chess2rt_amd/csrc
+BUILD      := build
+
+UNITS      := 0 1 2 3 4 5
+KOBJS      := $(foreach u,$(UNITS),$(BUILD)/c2rt_kernels_u$(u).o)
+HOBJS      := $(BUILD)/c2rt_api.o $(BUILD)/dsc.o $(BUILD)/scene.o $(BUILD)/host_api.o
+
+all: chess2rt_amd/libc2rt.so oracle/libc2rt_oracle.so
+
+$(BUILD):
+	mkdir -p $(BUILD)
+
+$(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -DC2RT_UNIT=$* -c $< -o $@
+
+$(BUILD)/c2rt_api.o: $(CSRC)/c2rt_api.cpp $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
+	g++ $(CXXFLAGS) -c $< -o $@
+
+$(BUILD)/%.o: $(CSRC)/host/%.cpp $(CSRC)/host/scene.hpp $(CSRC)/host/dsc.hpp include/c2rt.h include/c2rt_host.h | $(BUILD)
+	g++ $(CXXFLAGS) -c $< -o $@
+
+chess2rt_amd/libc2rt.so: $(KOBJS) $(HOBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
+
+# CPU oracle: plain C restatement of the reference algorithm (tests only)
+oracle/libc2rt_oracle.so: oracle/c2rt_oracle.c oracle/c2rt_oracle.h include/c2rt.h
+	$(CC) -O2 -std=gnu11 -fPIC -shared $(FPFLAGS) -Wall -o $@ oracle/c2rt_oracle.c -lm -lpthread
+
+clean:
+	rm -rf $(BUILD) chess2rt_amd/libc2rt.so oracle/libc2rt_oracle.so
+
+.PHONY: all clean

@@ -1,0 +1,503 @@
+/*
+ * c2rt_api.cpp — implementation of the C ABI in include/c2rt.h: context,
+ * scene validation + upload (SoA tables -> scalar-loadable records in HBM),
+ * frame / pixel-probe launches, strip de-interleave and display encode.
+ *
+ * There is no CPU fallback anywhere in this file: without a usable HIP
+ * device every entry point fails with C2RT_ERR_NO_DEVICE / C2RT_ERR_HIP.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "c2rt_device.h"
+
+using namespace c2rt;
+
+struct c2rt_ctx {
+    int device = 0;
+    std::string err;
+    hipStream_t stream = nullptr;
+
+    bool has_scene = false;
+    int csg_levels = 0;
+    DevGeom *geoms = nullptr;
+    DevNode *nodes = nullptr;
+    DevShader *shaders = nullptr;
+    DevTex *textures = nullptr;
+    DevLight *lights = nullptr;
+    float *texels = nullptr;
+    uint32_t n_nodes = 0, n_lights = 0;
+    float ambient[3] = {0, 0, 0};
+    uint32_t max_trace_depth = 0;
+
+    float *frame = nullptr;        /* staging frame for host-output renders */
+    size_t frame_floats = 0;
+    unsigned long long *counters = nullptr; /* [2] */
+    c2rt_trace_result *probe = nullptr;
+    uint8_t *srgb_lut = nullptr;   /* [4097] */
+    bool counters_valid = false;
+    hipStream_t counters_stream = nullptr;
+};
+
+namespace {
+
+int fail(c2rt_ctx *ctx, int status, const char *fmt, ...)
+{
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return status;
+}
+
+#define HIP_TRY(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return fail(ctx, C2RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int upload(c2rt_ctx *ctx, T **dst, const std::vector<T> &src)
+{
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(dst), bytes));
+    if (!src.empty()) HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return C2RT_OK;
+}
+
+bool is_csg(int t) { return t == C2RT_GEOM_CSG_UNION || t == C2RT_GEOM_CSG_INTER || t == C2RT_GEOM_CSG_DIFF; }
+
+/* nesting depth of the CsgOp tree under `g` (0 for primitives); -1 on a cycle
+ * or an out-of-range child */
+int csg_depth(const c2rt_scene_desc *s, int32_t g, std::vector<int> &state, std::vector<int> &memo)
+{
+    if (g < 0 || (uint32_t)g >= s->n_geoms) return -1;
+    if (state[g] == 1) return -1; /* on the current path: cycle */
+    if (state[g] == 2) return memo[g];
+    int d = 0;
+    if (is_csg(s->geom_type[g])) {
+        state[g] = 1;
+        const int l = csg_depth(s, s->geom_child[2 * g + 0], state, memo);
+        const int r = csg_depth(s, s->geom_child[2 * g + 1], state, memo);
+        if (l < 0 || r < 0) return -1;
+        d = 1 + (l > r ? l : r);
+    }
+    state[g] = 2;
+    memo[g] = d;
+    return d;
+}
+
+/* convertTo8bit_sRGB — rt/color.d:194-207 (note the 12.02) and the 4097-entry
+ * cache built by the module constructor rt/color.d:224-228 */
+void build_srgb_lut(uint8_t *lut)
+{
+    for (int i = 0; i < 4097; ++i) {
+        float x = i / 4096.0f;
+        uint8_t v;
+        if (x <= 0) v = 0;
+        else if (x >= 1) v = 255;
+        else {
+            if (x <= 0.0031308f) x = x * 12.02f;
+            else x = (float)(1.055 * std::pow((double)x, 1 / 2.4) - 0.055);
+            v = (uint8_t)(int)std::floor(x * 255.0f);
+        }
+        lut[i] = v;
+    }
+}
+
+uint32_t strip_h(const c2rt_render_opts *o) { return o->strip_height ? o->strip_height : 1u; }
+
+uint32_t local_rows_of(const c2rt_render_opts *o, uint32_t rank)
+{
+    if (o->strip_world <= 1) return o->height;
+    const uint32_t sh = strip_h(o);
+    const uint32_t n_strips = (o->height + sh - 1) / sh;
+    uint32_t rows = 0;
+    for (uint32_t s = rank; s < n_strips; s += o->strip_world) {
+        const uint32_t y0 = s * sh;
+        rows += (y0 + sh <= o->height) ? sh : (o->height - y0);
+    }
+    return rows;
+}
+
+int check_frame_args(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *o)
+{
+    if (!ctx) return C2RT_ERR_INVALID_ARG;
+    if (!cam || !o) return fail(ctx, C2RT_ERR_INVALID_ARG, "null camera or options");
+    if (!ctx->has_scene) return fail(ctx, C2RT_ERR_NO_SCENE, "no scene uploaded");
+    if (o->width == 0 || o->height == 0 || o->width > (1u << 16) || o->height > (1u << 16))
+        return fail(ctx, C2RT_ERR_INVALID_ARG, "bad frame size %ux%u", o->width, o->height);
+    if (o->taps != C2RT_TAPS_1 && o->taps != C2RT_TAPS_REF5 && o->taps != C2RT_TAPS_4)
+        return fail(ctx, C2RT_ERR_INVALID_ARG, "bad tap mode %u", o->taps);
+    if (o->strip_world > 1 && o->strip_rank >= o->strip_world)
+        return fail(ctx, C2RT_ERR_INVALID_ARG, "strip_rank %u >= strip_world %u", o->strip_rank, o->strip_world);
+    if (cam->dof && (cam->num_samples == 0 || cam->num_samples > 4096))
+        return fail(ctx, C2RT_ERR_LIMIT, "dof numSamples %u outside 1..4096", cam->num_samples);
+    if (!(cam->frame_width > 0) || !(cam->frame_height > 0))
+        return fail(ctx, C2RT_ERR_INVALID_ARG, "camera frame size must be positive");
+    return C2RT_OK;
+}
+
+void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *o, RenderParams &p)
+{
+    std::memset(&p, 0, sizeof p);
+    p.geoms = ctx->geoms;
+    p.nodes = ctx->nodes;
+    p.shaders = ctx->shaders;
+    p.textures = ctx->textures;
+    p.lights = ctx->lights;
+    p.texels = ctx->texels;
+    p.n_nodes = ctx->n_nodes;
+    p.n_lights = ctx->n_lights;
+    std::memcpy(p.ambient, ctx->ambient, sizeof p.ambient);
+    p.max_trace_depth = ctx->max_trace_depth;
+    p.cam = *cam;
+    p.width = o->width;
+    p.height = o->height;
+    p.taps = o->taps;
+    p.strip_height = strip_h(o);
+    p.strip_rank = o->strip_world > 1 ? o->strip_rank : 0;
+    p.strip_world = o->strip_world > 1 ? o->strip_world : 1;
+    p.local_rows = local_rows_of(o, p.strip_rank);
+    p.tiles_x = (o->width + kTileW - 1) / kTileW;
+    p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
+    p.seed = o->seed;
+}
+
+KernelVariant variant_of(const c2rt_ctx *ctx, const c2rt_camera_frame *cam)
+{
+    KernelVariant v;
+    v.csg_levels = ctx->csg_levels;
+    v.dof_or_stereo = cam->dof != 0 || cam->stereo_separation != 0;
+    return v;
+}
+
+int render_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_dev,
+                  hipStream_t stream)
+{
+    RenderParams p;
+    fill_params(ctx, cam, opts, p);
+    p.out = out_dev;
+    ctx->counters_valid = false;
+    if (opts->count_rays) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 2 * sizeof(unsigned long long), stream));
+        p.ray_counters = ctx->counters;
+    }
+    if (p.local_rows == 0) return C2RT_OK;
+    const int e = launch_render(p, variant_of(ctx, cam), stream);
+    if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
+    if (opts->count_rays) {
+        ctx->counters_valid = true;
+        ctx->counters_stream = stream;
+    }
+    return C2RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t c2rt_abi_version(void) { return C2RT_ABI_VERSION; }
+
+const char *c2rt_status_string(int status)
+{
+    switch (status) {
+    case C2RT_OK: return "ok";
+    case C2RT_ERR_INVALID_ARG: return "invalid argument";
+    case C2RT_ERR_NO_DEVICE: return "no usable GPU (this library has no CPU fallback)";
+    case C2RT_ERR_HIP: return "HIP runtime error";
+    case C2RT_ERR_UNSUPPORTED: return "unsupported feature";
+    case C2RT_ERR_LIMIT: return "device-path limit exceeded";
+    case C2RT_ERR_NO_SCENE: return "no scene uploaded";
+    case C2RT_ERR_CANCELLED: return "cancelled";
+    case C2RT_ERR_IO: return "I/O error";
+    case C2RT_ERR_PARSE: return "parse error";
+    default: return "unknown status";
+    }
+}
+
+const char *c2rt_last_error(const c2rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int c2rt_init(int device, c2rt_ctx **out)
+{
+    if (!out) return C2RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return C2RT_ERR_NO_DEVICE;
+    if (device >= count) return C2RT_ERR_NO_DEVICE;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return C2RT_ERR_NO_DEVICE;
+    c2rt_ctx *ctx = new c2rt_ctx();
+    ctx->device = device;
+    *out = ctx; /* handed out even on failure below so that c2rt_last_error works */
+    HIP_TRY(ctx, hipSetDevice(device));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counters), 2 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->probe), sizeof(c2rt_trace_result)));
+    uint8_t lut[4097];
+    build_srgb_lut(lut);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->srgb_lut), sizeof lut));
+    HIP_TRY(ctx, hipMemcpy(ctx->srgb_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    return C2RT_OK;
+}
+
+void c2rt_destroy(c2rt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    void *bufs[] = {ctx->geoms, ctx->nodes, ctx->shaders, ctx->textures, ctx->lights, ctx->texels,
+                    ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    delete ctx;
+}
+
+int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
+{
+    if (!ctx) return C2RT_ERR_INVALID_ARG;
+    if (!s) return fail(ctx, C2RT_ERR_INVALID_ARG, "null scene");
+    if (s->abi_version != C2RT_ABI_VERSION)
+        return fail(ctx, C2RT_ERR_INVALID_ARG, "scene abi_version %u != %u", s->abi_version, C2RT_ABI_VERSION);
+    if (s->gi_enabled) return fail(ctx, C2RT_ERR_UNSUPPORTED, "GIEnabled scenes (path tracing) are outside the hot path");
+    if ((s->n_geoms && (!s->geom_type || !s->geom_param || !s->geom_child)) ||
+        (s->n_textures && (!s->tex_type || !s->tex_color || !s->tex_param || !s->tex_scaling || !s->tex_width ||
+                           !s->tex_height || !s->tex_offset)) ||
+        (s->n_shaders && (!s->shader_type || !s->shader_color || !s->shader_texture || !s->shader_exponent ||
+                          !s->shader_strength)) ||
+        (s->n_lights && (!s->light_type || !s->light_pos || !s->light_color || !s->light_power)) ||
+        (s->n_nodes && (!s->node_geom || !s->node_shader || !s->node_transform)) || (s->n_texels && !s->texels))
+        return fail(ctx, C2RT_ERR_INVALID_ARG, "null table with non-zero count");
+    if (s->n_geoms >= (1u << 23)) return fail(ctx, C2RT_ERR_LIMIT, "too many geometries");
+
+    ctx->has_scene = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    /* geometries */
+    std::vector<DevGeom> geoms(s->n_geoms);
+    for (uint32_t g = 0; g < s->n_geoms; ++g) {
+        const int t = s->geom_type[g];
+        if (t < C2RT_GEOM_PLANE || t > C2RT_GEOM_CSG_DIFF) return fail(ctx, C2RT_ERR_UNSUPPORTED, "geometry %u: unknown type %d", g, t);
+        DevGeom &d = geoms[g];
+        std::memset(&d, 0, sizeof d);
+        d.type = t;
+        d.left = is_csg(t) ? s->geom_child[2 * g + 0] : -1;
+        d.right = is_csg(t) ? s->geom_child[2 * g + 1] : -1;
+        for (int i = 0; i < 4; ++i) d.p[i] = s->geom_param[4 * g + i];
+    }
+    std::vector<int> state(s->n_geoms, 0), memo(s->n_geoms, 0);
+    int levels = 0;
+
+    /* textures: texel pool repacked to float4 */
+    std::vector<DevTex> textures(s->n_textures);
+    for (uint32_t t = 0; t < s->n_textures; ++t) {
+        const int ty = s->tex_type[t];
+        if (ty < C2RT_TEX_CHECKER || ty > C2RT_TEX_BITMAP) return fail(ctx, C2RT_ERR_UNSUPPORTED, "texture %u: unknown type %d", t, ty);
+        DevTex &d = textures[t];
+        std::memset(&d, 0, sizeof d);
+        d.type = ty;
+        d.scaling = s->tex_scaling[t];
+        for (int i = 0; i < 18; ++i) d.color[i] = s->tex_color[18 * t + i];
+        for (int i = 0; i < 6; ++i) d.param[i] = s->tex_param[6 * t + i];
+        if (ty == C2RT_TEX_BITMAP) {
+            d.width = s->tex_width[t];
+            d.height = s->tex_height[t];
+            d.offset = s->tex_offset[t];
+            if ((uint64_t)d.width * d.height + d.offset > s->n_texels)
+                return fail(ctx, C2RT_ERR_INVALID_ARG, "texture %u: texels out of the pool", t);
+            if (d.width >= (1u << 24) || d.height >= (1u << 24)) return fail(ctx, C2RT_ERR_LIMIT, "texture %u too large", t);
+        }
+    }
+    std::vector<float> texels4((size_t)s->n_texels * 4);
+    for (uint64_t i = 0; i < s->n_texels; ++i) {
+        texels4[4 * i + 0] = s->texels[3 * i + 0];
+        texels4[4 * i + 1] = s->texels[3 * i + 1];
+        texels4[4 * i + 2] = s->texels[3 * i + 2];
+        texels4[4 * i + 3] = 0.0f;
+    }
+
+    /* shaders */
+    std::vector<DevShader> shaders(s->n_shaders);
+    for (uint32_t i = 0; i < s->n_shaders; ++i) {
+        const int ty = s->shader_type[i];
+        if (ty != C2RT_SHADER_LAMBERT && ty != C2RT_SHADER_PHONG) return fail(ctx, C2RT_ERR_UNSUPPORTED, "shader %u: unknown type %d", i, ty);
+        DevShader &d = shaders[i];
+        std::memset(&d, 0, sizeof d);
+        d.type = ty;
+        d.tex = s->shader_texture[i];
+        if (d.tex >= (int32_t)s->n_textures) return fail(ctx, C2RT_ERR_INVALID_ARG, "shader %u: texture index %d out of range", i, d.tex);
+        if (d.tex < 0) d.tex = -1;
+        for (int c = 0; c < 3; ++c) d.color[c] = s->shader_color[3 * i + c];
+        d.strength = s->shader_strength[i];
+        d.exponent = s->shader_exponent[i];
+    }
+
+    /* lights */
+    std::vector<DevLight> lights(s->n_lights);
+    for (uint32_t i = 0; i < s->n_lights; ++i) {
+        if (s->light_type[i] != C2RT_LIGHT_POINT) return fail(ctx, C2RT_ERR_UNSUPPORTED, "light %u: unknown type %d", i, s->light_type[i]);
+        DevLight &d = lights[i];
+        std::memset(&d, 0, sizeof d);
+        for (int c = 0; c < 3; ++c) d.pos[c] = s->light_pos[3 * i + c];
+        /* Light.color(): lightColor * lightPower — rt/light.d:11-14 */
+        for (int c = 0; c < 3; ++c) d.color[c] = s->light_color[3 * i + c] * s->light_power[i];
+        /* lightColor.intensity() != 0 — rt/shader.d:88, rt/color.d:141-144 */
+        const float intensity = (d.color[0] + d.color[1] + d.color[2]) / 3;
+        d.lit = intensity != 0 ? 1u : 0u;
+    }
+
+    /* nodes */
+    std::vector<DevNode> nodes(s->n_nodes);
+    for (uint32_t n = 0; n < s->n_nodes; ++n) {
+        DevNode &d = nodes[n];
+        std::memset(&d, 0, sizeof d);
+        d.geom = s->node_geom[n];
+        d.shader = s->node_shader[n];
+        if (d.shader < 0 || (uint32_t)d.shader >= s->n_shaders) return fail(ctx, C2RT_ERR_INVALID_ARG, "node %u: shader index %d out of range", n, d.shader);
+        const int depth = csg_depth(s, d.geom, state, memo);
+        if (depth < 0) return fail(ctx, C2RT_ERR_INVALID_ARG, "node %u: geometry index out of range or cyclic CSG", n);
+        if (depth > C2RT_MAX_CSG_DEPTH) return fail(ctx, C2RT_ERR_LIMIT, "node %u: CSG nesting %d > %d", n, depth, C2RT_MAX_CSG_DEPTH);
+        if (depth > levels) levels = depth;
+        const double *t = s->node_transform + 30 * (size_t)n;
+        std::memcpy(d.m, t, 9 * sizeof(double));
+        std::memcpy(d.inv, t + 9, 9 * sizeof(double));
+        std::memcpy(d.tinv, t + 18, 9 * sizeof(double));
+        std::memcpy(d.off, t + 27, 3 * sizeof(double));
+        static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        bool ident = true;
+        for (int i = 0; i < 9; ++i) ident = ident && d.m[i] == I[i] && d.inv[i] == I[i] && d.tinv[i] == I[i];
+        if (ident) d.flags |= kNodeIdentityMatrix;
+        if (d.off[0] == 0 && d.off[1] == 0 && d.off[2] == 0) d.flags |= kNodeZeroOffset;
+    }
+
+    int st;
+    if ((st = upload(ctx, &ctx->geoms, geoms)) != C2RT_OK) return st;
+    if ((st = upload(ctx, &ctx->textures, textures)) != C2RT_OK) return st;
+    if ((st = upload(ctx, &ctx->texels, texels4)) != C2RT_OK) return st;
+    if ((st = upload(ctx, &ctx->shaders, shaders)) != C2RT_OK) return st;
+    if ((st = upload(ctx, &ctx->lights, lights)) != C2RT_OK) return st;
+    if ((st = upload(ctx, &ctx->nodes, nodes)) != C2RT_OK) return st;
+    ctx->n_nodes = s->n_nodes;
+    ctx->n_lights = s->n_lights;
+    std::memcpy(ctx->ambient, s->ambient, sizeof ctx->ambient);
+    ctx->max_trace_depth = s->max_trace_depth;
+    ctx->csg_levels = levels;
+    ctx->has_scene = true;
+    ctx->err.clear();
+    return C2RT_OK;
+}
+
+uint32_t c2rt_local_rows(const c2rt_render_opts *opts)
+{
+    if (!opts) return 0;
+    if (opts->strip_world > 1 && opts->strip_rank >= opts->strip_world) return 0;
+    return local_rows_of(opts, opts->strip_world > 1 ? opts->strip_rank : 0);
+}
+
+int c2rt_render_frame_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts,
+                             float *out_rgb_dev, void *hip_stream)
+{
+    int st = check_frame_args(ctx, cam, opts);
+    if (st != C2RT_OK) return st;
+    if (!out_rgb_dev) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return render_device(ctx, cam, opts, out_rgb_dev, static_cast<hipStream_t>(hip_stream));
+}
+
+int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_rgb,
+                      const volatile uint8_t *stop_flag)
+{
+    int st = check_frame_args(ctx, cam, opts);
+    if (st != C2RT_OK) return st;
+    if (!out_rgb) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
+    /* isStopReq() before the pass — rt/renderer.d:129 */
+    if (stop_flag && *stop_flag) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested before the frame");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t floats = (size_t)c2rt_local_rows(opts) * opts->width * 3;
+    if (floats > ctx->frame_floats) {
+        if (ctx->frame) { (void)hipFree(ctx->frame); ctx->frame = nullptr; ctx->frame_floats = 0; }
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->frame), floats * sizeof(float)));
+        ctx->frame_floats = floats;
+    }
+    st = render_device(ctx, cam, opts, ctx->frame, ctx->stream);
+    if (st != C2RT_OK) return st;
+    if (floats) HIP_TRY(ctx, hipMemcpyAsync(out_rgb, ctx->frame, floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return C2RT_OK;
+}
+
+int c2rt_get_ray_stats(c2rt_ctx *ctx, c2rt_ray_stats *out)
+{
+    if (!ctx || !out) return C2RT_ERR_INVALID_ARG;
+    if (!ctx->counters_valid) return fail(ctx, C2RT_ERR_INVALID_ARG, "last render did not count rays");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->counters_stream));
+    unsigned long long h[2];
+    HIP_TRY(ctx, hipMemcpy(h, ctx->counters, sizeof h, hipMemcpyDeviceToHost));
+    out->primary_rays = h[0];
+    out->shadow_rays = h[1];
+    return C2RT_OK;
+}
+
+int c2rt_render_pixel(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, int x, int y,
+                      c2rt_trace_result *out)
+{
+    int st = check_frame_args(ctx, cam, opts);
+    if (st != C2RT_OK) return st;
+    if (!out) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RenderParams p;
+    fill_params(ctx, cam, opts, p);
+    p.probe_x = x;
+    p.probe_y = y;
+    p.probe_out = ctx->probe;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->probe, 0, sizeof(c2rt_trace_result), ctx->stream));
+    const int e = launch_probe(p, variant_of(ctx, cam), ctx->stream);
+    if (e != 0) return fail(ctx, C2RT_ERR_HIP, "probe kernel launch: %s", hipGetErrorString((hipError_t)e));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->probe, sizeof *out, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return C2RT_OK;
+}
+
+int c2rt_deinterleave_strips(c2rt_ctx *ctx, const float *gathered_dev, float *frame_dev, uint32_t width,
+                             uint32_t height, uint32_t strip_height, uint32_t world, void *hip_stream)
+{
+    if (!ctx) return C2RT_ERR_INVALID_ARG;
+    if (!gathered_dev || !frame_dev || width == 0 || height == 0 || world == 0)
+        return fail(ctx, C2RT_ERR_INVALID_ARG, "bad de-interleave arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    c2rt_render_opts o;
+    std::memset(&o, 0, sizeof o);
+    o.width = width;
+    o.height = height;
+    o.strip_height = strip_height;
+    o.strip_world = world;
+    const uint32_t sh = strip_h(&o);
+    const uint32_t rows_pad = world > 1 ? local_rows_of(&o, 0) : height; /* rank 0 always owns the most rows */
+    const int e = launch_deinterleave(gathered_dev, frame_dev, width, height, sh, world, rows_pad, hip_stream);
+    if (e != 0) return fail(ctx, C2RT_ERR_HIP, "de-interleave launch: %s", hipGetErrorString((hipError_t)e));
+    return C2RT_OK;
+}
+
+int c2rt_encode_rgb32(c2rt_ctx *ctx, const float *frame_dev, uint32_t *out_dev, uint64_t n_pixels, void *hip_stream)
+{
+    if (!ctx) return C2RT_ERR_INVALID_ARG;
+    if (!frame_dev || !out_dev) return fail(ctx, C2RT_ERR_INVALID_ARG, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n_pixels == 0) return C2RT_OK;
+    const int e = launch_encode_rgb32(frame_dev, out_dev, n_pixels, ctx->srgb_lut, hip_stream);
+    if (e != 0) return fail(ctx, C2RT_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
+    return C2RT_OK;
+}
+
+} /* extern "C" */

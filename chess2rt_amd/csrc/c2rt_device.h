@@ -1,0 +1,120 @@
+/*
+ * c2rt_device.h — device-side table layout and launch interface shared by
+ * c2rt_kernels.hip (kernels) and c2rt_api.cpp (C-ABI implementation).
+ *
+ * The public SoA tables of c2rt_scene_desc are repacked at upload into small
+ * 16-byte-aligned records: every lane of a wavefront walks the SAME node /
+ * geometry / light at the same time, so the records are fetched with scalar
+ * (SMEM) loads into SGPRs — one s_load per record, no VGPRs, no LDS — and only
+ * texels and the frame go through the vector memory path.
+ */
+#ifndef C2RT_DEVICE_H
+#define C2RT_DEVICE_H
+
+#include <stdint.h>
+
+#include "../../include/c2rt.h"
+
+namespace c2rt {
+
+constexpr int kMaxCsgHits = C2RT_MAX_CSG_HITS; /* per CSG child per ray */
+constexpr int kCsgEntries = 2 * kMaxCsgHits;
+constexpr int kTileW = 8, kTileH = 8;          /* one wavefront = one 8x8 pixel tile */
+constexpr int kWave = 64;
+/* LDS bytes one wavefront needs per CSG nesting level: dist[16][64] + tag[16][64] */
+constexpr int kCsgLdsPerLevel = kCsgEntries * kWave * (8 + 4);
+
+struct alignas(16) DevGeom {       /* 48 B */
+    int32_t type, left, right, pad;
+    double p[4];                   /* plane: y, limit | sphere: c, R | cube: c, side */
+};
+
+enum NodeFlags : uint32_t {
+    kNodeIdentityMatrix = 1u,      /* transform == inverse == I: skip the 3x3 products (exact) */
+    kNodeZeroOffset = 2u,          /* offset == 0: skip the subtraction/addition */
+};
+
+struct alignas(16) DevNode {       /* 256 B */
+    int32_t geom, shader;
+    uint32_t flags, pad;
+    double inv[9];                 /* inverseTransform */
+    double m[9];                   /* transform */
+    double tinv[9];                /* transposedInverse */
+    double off[3];
+};
+
+struct alignas(16) DevShader {     /* 32 B */
+    int32_t type, tex;
+    float color[3];
+    float strength;
+    double exponent;
+};
+
+struct alignas(16) DevTex {        /* 144 B */
+    int32_t type;
+    uint32_t width, height;
+    float scaling;
+    uint64_t offset;               /* first texel of the bitmap in the float4 pool */
+    float color[18];
+    double param[6];
+};
+
+struct alignas(16) DevLight {      /* 48 B */
+    double pos[3];
+    float color[3];                /* lightColor * lightPower (rt/light.d:11-14) */
+    uint32_t lit;                  /* intensity(color) != 0 */
+    uint32_t pad[2];
+};
+
+/* Kernel argument block (passed by value: lives in the kernarg segment and is
+ * read with scalar loads). */
+struct RenderParams {
+    const DevGeom *geoms;
+    const DevNode *nodes;
+    const DevShader *shaders;
+    const DevTex *textures;
+    const DevLight *lights;
+    const float *texels;           /* float4 per texel (rgb, pad): one dwordx4 gather per tap */
+    uint32_t n_nodes, n_lights;
+    float ambient[3];
+    uint32_t max_trace_depth;
+
+    c2rt_camera_frame cam;
+
+    uint32_t width, height;        /* frame */
+    uint32_t taps;
+    uint32_t strip_height, strip_rank, strip_world;
+    uint32_t local_rows;
+    uint32_t tiles_x, tiles_y;     /* tile grid over the LOCAL rows */
+    uint64_t seed;
+    float *out;                    /* local_rows * width * 3 floats */
+    unsigned long long *ray_counters; /* [2] primary, shadow (nullable) */
+    /* pixel probe */
+    int32_t probe_x, probe_y;
+    c2rt_trace_result *probe_out;
+};
+
+/* Scene feature bits selecting the kernel instance (so that a plane-only
+ * scene does not pay the registers of the CSG path). */
+struct KernelVariant {
+    int csg_levels;                /* 0..C2RT_MAX_CSG_DEPTH */
+    bool dof_or_stereo;
+};
+
+/* implemented in c2rt_kernels.hip; return hipError_t as int */
+template <int LEVELS>
+int launch_render_level(const RenderParams &p, bool dof_or_stereo, void *stream);
+template <> int launch_render_level<0>(const RenderParams &, bool, void *);
+template <> int launch_render_level<1>(const RenderParams &, bool, void *);
+template <> int launch_render_level<2>(const RenderParams &, bool, void *);
+template <> int launch_render_level<3>(const RenderParams &, bool, void *);
+template <> int launch_render_level<4>(const RenderParams &, bool, void *);
+int launch_render(const RenderParams &p, const KernelVariant &v, void *stream);
+int launch_probe(const RenderParams &p, const KernelVariant &v, void *stream);
+int launch_deinterleave(const float *gathered, float *frame, uint32_t width, uint32_t height,
+                        uint32_t strip_height, uint32_t world, uint32_t rows_pad, void *stream);
+int launch_encode_rgb32(const float *frame, uint32_t *out, uint64_t n_pixels,
+                        const uint8_t *lut_dev, void *stream);
+
+} // namespace c2rt
+#endif

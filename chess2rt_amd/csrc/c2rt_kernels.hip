@@ -1,0 +1,865 @@
+/*
+ * c2rt_kernels.hip — the per-pixel ray-trace hot path of Chess2RT, written
+ * for gfx950 (MI355X, CDNA4).  Not a port: the reference is a D class
+ * hierarchy with virtual dispatch over a linear node list; this is a
+ * wave-synchronous trace where
+ *
+ *   - one 64-lane wavefront owns one 8x8 pixel tile (one workgroup = one
+ *     wave; the grid has >>256 workgroups, dealt round-robin to the 8 XCDs, and
+ *     the block -> tile map gives each XCD every 8th tile ROW so that texel
+ *     reuse stays inside one XCD's L2 while all XCDs see the same sky/floor mix);
+ *   - every lane walks the SAME node / geometry / light at the same time, so
+ *     the scene records are read with scalar loads into SGPRs and the type
+ *     dispatch is a scalar branch, never a divergent one;
+ *   - CSG hit lists live in LDS, one [entry][lane] slab per nesting level
+ *     (bank = lane, conflict-free for any per-lane entry index); only
+ *     (dist, tag) is kept per hit and the winning hit is re-derived, which
+ *     keeps the slab at 12 KiB per wave and level;
+ *   - geometry is fp64 and colour fp32 in the reference's operation order
+ *     (built with -ffp-contract=off), because checker edges, shadow
+ *     terminators and CSG boundaries flip on 1-ulp differences.
+ *
+ * What each function restates is cited as file:line of /root/reference/source.
+ */
+#include <hip/hip_runtime.h>
+
+#include "c2rt_device.h"
+
+namespace c2rt {
+namespace {
+
+#define DEV __device__ __forceinline__
+#ifndef C2RT_OCC
+#define C2RT_OCC
+#endif
+
+/* ------------------------------------------------------------------ */
+/* small vector types (gfm vec3d / rt Color semantics)                  */
+/* ------------------------------------------------------------------ */
+
+struct D3 { double x, y, z; };
+DEV D3 mk(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV D3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+DEV D3 operator+(D3 a, D3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV D3 operator-(D3 a, D3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV D3 operator*(D3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+DEV D3 operator-(D3 a) { return mk(-a.x, -a.y, -a.z); }
+/* gfm dot/squaredMagnitude start from `sum = 0`; 0 + x differs from x only in
+ * the sign of an exact zero, which no consumer on this path observes. */
+DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV double sqmag(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+DEV double mag(D3 a) { return sqrt(sqmag(a)); }
+DEV D3 normalized(D3 a) { double inv = 1.0 / mag(a); return mk(a.x * inv, a.y * inv, a.z * inv); }
+/* mul(v, M): row vector x matrix — rt/imported_types.d:13-20 */
+DEV D3 mulvm(D3 v, const double *m)
+{
+    return mk(v.x * m[0] + v.y * m[3] + v.z * m[6],
+              v.x * m[1] + v.y * m[4] + v.z * m[7],
+              v.x * m[2] + v.y * m[5] + v.z * m[8]);
+}
+
+struct F3 { float r, g, b; };
+DEV F3 mkf(float r, float g, float b) { F3 c; c.r = r; c.g = g; c.b = b; return c; }
+DEV F3 ldf3(const float *p) { return mkf(p[0], p[1], p[2]); }
+DEV F3 operator+(F3 a, F3 b) { return mkf(a.r + b.r, a.g + b.g, a.b + b.b); }
+DEV F3 operator*(F3 a, F3 b) { return mkf(a.r * b.r, a.g * b.g, a.b * b.b); }
+DEV F3 operator*(F3 a, float f) { return mkf(a.r * f, a.g * f, a.b * f); }
+DEV F3 operator/(F3 a, float f) { return mkf(a.r / f, a.g / f, a.b / f); }
+
+/* x86 cvttsd2si / cvttss2si results for out-of-range inputs, which is what
+ * the reference binary computes for cast(int) / cast(size_t). */
+DEV int d2i_x86(double d)
+{
+    return (d > -2147483649.0 && d < 2147483648.0) ? (int)d : (int)0x80000000;
+}
+
+/* ------------------------------------------------------------------ */
+/* hit record                                                           */
+/* ------------------------------------------------------------------ */
+
+struct Hit {          /* IntersectionData — rt/intersectable.d:6-33 (dNdx/dNdy are dead on this path) */
+    D3 p, n;
+    double dist, u, v;
+    int g;
+};
+
+/* what a caller needs back from an intersect call */
+enum Need { kBool = 0, kPoint = 1, kFull = 2 };
+
+/* what the trace needs below the shading level: table bases (SGPRs), the
+ * wave's CSG slabs and the lane.  Deliberately NOT a pointer to the kernel
+ * arguments, so that out-of-line CSG levels do not force them into scratch. */
+struct Ctx {
+    const DevGeom *geoms;
+    const DevNode *nodes;
+    uint32_t n_nodes;
+    char *lds;        /* this wave's CSG slabs */
+    int lane;
+};
+
+/* ------------------------------------------------------------------ */
+/* primitives                                                           */
+/* ------------------------------------------------------------------ */
+
+/* Plane.intersect — rt/geometry.d:30-59 */
+template <int NEED>
+DEV bool plane_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
+{
+    const double y = G->p[0], limit = G->p[1];
+    if ((o.y > y && d.y > -1e-9) || (o.y < y && d.y < 1e-9)) return false;
+    const double mult = (o.y - y) / -d.y;
+    if (mult > h.dist) return false;
+    const D3 p = o + d * mult;
+    if (fabs(p.x) > limit || fabs(p.z) > limit) return false;
+    h.dist = mult;
+    if (NEED >= kPoint) { h.p = p; h.g = gid; }
+    if (NEED == kFull) { h.n = mk(0, 1, 0); h.u = p.x; h.v = p.z; }
+    return true;
+}
+
+/* Sphere.intersect — rt/geometry.d:92-125 */
+template <int NEED>
+DEV bool sphere_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
+{
+    const D3 c = ld3(G->p);
+    const double R = G->p[3];
+    const D3 H = o - c;
+    const double A = sqmag(d);
+    const double B = 2 * dot(H, d);
+    const double C = sqmag(H) - R * R;
+    const double Dscr = B * B - 4 * A * C;
+    if (Dscr < 0) return false;
+    const double sq = sqrt(Dscr);
+    const double x1 = (-B + sq) / (2 * A);
+    const double x2 = (-B - sq) / (2 * A);
+    double sol = x2;
+    if (sol < 0) sol = x1;
+    if (sol < 0) return false;
+    if (sol > h.dist) return false;
+    h.dist = sol;
+    if (NEED >= kPoint) {
+        const D3 p = o + d * sol;
+        h.p = p;
+        h.g = gid;
+        if (NEED == kFull) {
+            h.n = normalized(p - c);
+            const double angle = atan2(p.z - c.z, p.x - c.x);
+            constexpr double PI = 3.14159265358979323846;
+            h.u = (PI + angle) / (2 * PI);
+            h.v = 1.0 - (PI / 2 + asin((p.y - c.y) / R)) / PI;
+        }
+    }
+    return true;
+}
+
+/* Cube.intersectCubeSide — rt/geometry.d:198-235, for the face pair whose
+ * axis is `ay` after the project() permutation; (ax, az) are the other two
+ * axes in permuted order.  Arithmetic is component-wise, so it is evaluated
+ * in place instead of permuting (project/unproject, rt/imported_types.d:44-60). */
+template <int NEED>
+DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, double cx,
+                    double oz, double dz, double cz, double halfSide, D3 o, D3 d,
+                    Hit &h, int axis, int &hit_axis, double &hit_side)
+{
+    if (fabs(dy) < 1e-9) return false;
+    bool found = false;
+#pragma unroll
+    for (int side = -1; side <= 1; side += 2) {
+        const double mult = (oy - (cy + side * halfSide)) / -dy;
+        if (mult < 0) continue;
+        if (mult > h.dist) continue;
+        const double px = ox + dx * mult, pz = oz + dz * mult;
+        if (px < cx - halfSide || px > cx + halfSide || pz < cz - halfSide || pz > cz + halfSide) continue;
+        h.dist = mult;
+        if (NEED >= kPoint) h.p = o + d * mult;
+        if (NEED == kFull) {
+            hit_axis = axis;
+            hit_side = side;
+            h.u = px - cx;
+            h.v = pz - cz;
+        }
+        found = true;
+    }
+    return found;
+}
+
+/* Cube.intersect — rt/geometry.d:172-196 */
+template <int NEED>
+DEV bool cube_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
+{
+    const D3 c = ld3(G->p);
+    const double halfSide = G->p[3] * 0.5;
+    int axis = 1;
+    double side = 0;
+    /* Y faces; X faces = project(1,0,2): (y,x,z); Z faces = project(0,2,1): (x,z,y) */
+    bool found = cube_sides<NEED>(o.y, d.y, c.y, o.x, d.x, c.x, o.z, d.z, c.z, halfSide, o, d, h, 1, axis, side);
+    found |= cube_sides<NEED>(o.x, d.x, c.x, o.y, d.y, c.y, o.z, d.z, c.z, halfSide, o, d, h, 0, axis, side);
+    found |= cube_sides<NEED>(o.z, d.z, c.z, o.x, d.x, c.x, o.y, d.y, c.y, halfSide, o, d, h, 2, axis, side);
+    if (found) {
+        if (NEED >= kPoint) h.g = gid;
+        if (NEED == kFull) h.n = mk(axis == 0 ? side : 0.0, axis == 1 ? side : 0.0, axis == 2 ? side : 0.0);
+    }
+    return found;
+}
+
+/* isInside — rt/geometry.d:25-28,127-130,165-170,334-337 */
+template <int LEVEL>
+DEV bool geom_is_inside(const Ctx &cx, int gid, D3 p)
+{
+    const DevGeom *G = cx.geoms + gid;
+    const int type = G->type;
+    if (type == C2RT_GEOM_SPHERE) {
+        return sqmag(ld3(G->p) - p) < G->p[3] * G->p[3];
+    } else if (type == C2RT_GEOM_CUBE) {
+        const double hs = G->p[3] * 0.5;
+        return fabs(p.x - G->p[0]) <= hs && fabs(p.y - G->p[1]) <= hs && fabs(p.z - G->p[2]) <= hs;
+    } else if (type == C2RT_GEOM_PLANE) {
+        return false;
+    } else {
+        if constexpr (LEVEL > 0) {
+            const bool a = geom_is_inside<LEVEL - 1>(cx, G->left, p);
+            const bool b = geom_is_inside<LEVEL - 1>(cx, G->right, p);
+            return type == C2RT_GEOM_CSG_UNION ? (a || b) : (type == C2RT_GEOM_CSG_INTER ? (a && b) : (a && !b));
+        } else {
+            return false;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* CSG — rt/geometry.d:243-403                                          */
+/* ------------------------------------------------------------------ */
+
+template <int LEVEL, int NEED>
+__device__ bool geom_intersect(const Ctx &cx, int gid, D3 o, D3 d, Hit &h);
+
+/* CsgOp.intersect (+ CsgDiff.intersect) for a CSG whose subtree has at most
+ * LEVEL nesting levels.  The hit lists of findAllIntersections
+ * (rt/geometry.d:271-290) are kept in this level's LDS slab as
+ * (dist, tag = leaf<<8 | side<<4 | k); they are concatenated left-then-right
+ * and shell-sorted exactly as util/array.d:95-111 does (same tie behaviour),
+ * walked with the in/out toggles of rt/geometry.d:303-329 (including the
+ * `current.g is left` leaf-identity test), and the winning hit is then
+ * re-derived by replaying its child's stepping up to k. */
+template <int LEVEL, int NEED>
+__device__ bool csg_intersect(const Ctx &cx, const DevGeom *G, D3 o, D3 d, Hit &h)
+{
+    static_assert(LEVEL >= 1, "CSG needs a slab");
+    double *ldist = reinterpret_cast<double *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel) + cx.lane;
+    uint32_t *ltag = reinterpret_cast<uint32_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
+    const int type = G->type, left = G->left, right = G->right;
+
+    int nL = 0, nR = 0;
+    int n = 0;
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const int child = side ? right : left;
+        D3 oo = o;
+        double cur = 0;
+        int k = 0;
+        while (k < kMaxCsgHits) {
+            Hit t;
+            t.dist = 1e99;
+            if (!geom_intersect<LEVEL - 1, kPoint>(cx, child, oo, d, t)) break;
+            t.dist += cur;
+            cur = t.dist;
+            oo = t.p + d * 1e-6;
+            ldist[(n + k) * kWave] = t.dist;
+            ltag[(n + k) * kWave] = ((uint32_t)t.g << 8) | ((uint32_t)side << 4) | (uint32_t)k;
+            ++k;
+        }
+        if (side == 0) nL = k; else nR = k;
+        n += k;
+        /* exact shortcuts: with no left hit inL stays false, so Inter and Diff
+         * can never fire; with no right hit Inter cannot either. */
+        if (side == 0 && k == 0 && type != C2RT_GEOM_CSG_UNION) return false;
+        if (side == 1 && k == 0 && type == C2RT_GEOM_CSG_INTER) return false;
+    }
+
+    /* sort — util/array.d:95-111 (index rewound by the inner while) */
+    for (int inc = n / 2; inc;) {
+        for (int i = 0; i < n; ++i) {
+            const double ed = ldist[i * kWave];
+            const uint32_t et = ltag[i * kWave];
+            while (i >= inc && ldist[(i - inc) * kWave] > ed) {
+                ldist[i * kWave] = ldist[(i - inc) * kWave];
+                ltag[i * kWave] = ltag[(i - inc) * kWave];
+                i -= inc;
+            }
+            ldist[i * kWave] = ed;
+            ltag[i * kWave] = et;
+        }
+        inc = (inc == 2) ? 1 : (int)(inc * 5.0 / 11);
+    }
+
+    bool inL = (nL & 1) != 0, inR = (nR & 1) != 0;
+    int win = -1;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t tag = ltag[i * kWave];
+        if ((int)(tag >> 8) == left) inL = !inL; else inR = !inR;
+        const bool in = type == C2RT_GEOM_CSG_UNION ? (inL || inR)
+                      : (type == C2RT_GEOM_CSG_INTER ? (inL && inR) : (inL && !inR));
+        if (in) { win = i; break; }
+    }
+    if (win < 0) return false;
+    const double wdist = ldist[win * kWave];
+    if (wdist > h.dist) return false;
+    if (NEED == kBool) { h.dist = wdist; return true; }
+
+    /* re-derive the winning IntersectionData (data = current, rt/geometry.d:326) */
+    const uint32_t wtag = ltag[win * kWave];
+    const int wside = (wtag >> 4) & 1, wk = wtag & 15;
+    const int child = wside ? right : left;
+    D3 oo = o;
+    double cur = 0;
+    for (int i = 0; i < wk; ++i) {
+        Hit t;
+        t.dist = 1e99;
+        geom_intersect<LEVEL - 1, kPoint>(cx, child, oo, d, t);
+        t.dist += cur;
+        cur = t.dist;
+        oo = t.p + d * 1e-6;
+    }
+    Hit t;
+    t.dist = 1e99;
+    geom_intersect<LEVEL - 1, NEED>(cx, child, oo, d, t);
+    t.dist += cur;
+    h = t;
+
+    if (NEED == kFull && type == C2RT_GEOM_CSG_DIFF) { /* CsgDiff.intersect — rt/geometry.d:382-397 */
+        if (geom_is_inside<LEVEL - 1>(cx, right, h.p - d * 1e-6) != geom_is_inside<LEVEL - 1>(cx, right, h.p + d * 1e-6))
+            h.n = -h.n;
+    }
+    return true;
+}
+
+/* levels >= 2 are real calls so that code size stays linear in the depth */
+template <int LEVEL, int NEED>
+__device__ __noinline__ bool csg_intersect_call(const Ctx &cx, const DevGeom *G, D3 o, D3 d, Hit &h)
+{
+    return csg_intersect<LEVEL, NEED>(cx, G, o, d, h);
+}
+
+/* Geometry.intersect: `gid` is wave-uniform, so this is a scalar branch. */
+template <int LEVEL, int NEED>
+__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, D3 o, D3 d, Hit &h)
+{
+    const DevGeom *G = cx.geoms + gid;
+    const int type = G->type;
+    if (type == C2RT_GEOM_PLANE) return plane_intersect<NEED>(G, gid, o, d, h);
+    if (type == C2RT_GEOM_SPHERE) return sphere_intersect<NEED>(G, gid, o, d, h);
+    if (type == C2RT_GEOM_CUBE) return cube_intersect<NEED>(G, gid, o, d, h);
+    if constexpr (LEVEL >= 2) {
+        return csg_intersect_call<LEVEL, NEED>(cx, G, o, d, h);
+    } else if constexpr (LEVEL == 1) {
+        return csg_intersect<1, NEED>(cx, G, o, d, h);
+    } else {
+        return false;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* nodes — rt/node.d:23-49, rt/transform.d:57-86                         */
+/* ------------------------------------------------------------------ */
+
+/* The world ray normalised once for every node whose matrix is the identity:
+ * undoDirection(dir) == dir there, so `magnitude` and `normalize`
+ * (rt/node.d:34-36) give the same bits for all of them. */
+struct RayW {
+    D3 o, d;
+    D3 dn;      /* d * (1/|d|) */
+    double len; /* |d| */
+};
+DEV RayW make_ray(D3 o, D3 d)
+{
+    RayW r;
+    r.o = o;
+    r.d = d;
+    r.len = mag(d);
+    const double inv = 1.0 / r.len;
+    r.dn = mk(d.x * inv, d.y * inv, d.z * inv);
+    return r;
+}
+
+/* Node.intersect; `best.dist` is data.dist (world units) in and out. */
+template <int LEVELS, int NEED>
+DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &best)
+{
+    const uint32_t flags = N->flags;
+    D3 oc = ray.o, dc;
+    double len;
+    if (!(flags & kNodeZeroOffset)) oc = oc - ld3(N->off);
+    if (flags & kNodeIdentityMatrix) {
+        dc = ray.dn;
+        len = ray.len;
+    } else {
+        oc = mulvm(oc, N->inv);
+        const D3 dd = mulvm(ray.d, N->inv);
+        len = mag(dd);
+        const double inv = 1.0 / len;
+        dc = mk(dd.x * inv, dd.y * inv, dd.z * inv);
+    }
+    Hit h;
+    h.dist = best.dist * len;
+    if (!geom_intersect<LEVELS, NEED>(cx, N->geom, oc, dc, h)) return false;
+    if (NEED == kBool) return true;
+    best.dist = h.dist / len;
+    best.g = h.g;
+    best.u = h.u;
+    best.v = h.v;
+    if (flags & kNodeIdentityMatrix) {
+        best.n = normalized(h.n);
+        best.p = h.p;
+    } else {
+        best.n = normalized(mulvm(h.n, N->tinv));
+        best.p = mulvm(h.p, N->m);
+    }
+    if (!(flags & kNodeZeroOffset)) best.p = best.p + ld3(N->off);
+    return true;
+}
+
+/* Scene.testVisibility — rt/scene.d:62-78 */
+template <int LEVELS>
+DEV bool test_visibility(const Ctx &cx, D3 from, D3 to)
+{
+    const D3 dir = normalized(to - from);
+    const RayW ray = make_ray(from, dir);
+    Hit temp;
+    temp.dist = mag(to - from);
+    const uint32_t nn = cx.n_nodes;
+    for (uint32_t n = 0; n < nn; ++n)
+        if (node_intersect<LEVELS, kBool>(cx, cx.nodes + n, ray, temp)) return false;
+    return true;
+}
+
+/* ------------------------------------------------------------------ */
+/* textures — rt/texture.d, rt/bitmap.d                                  */
+/* ------------------------------------------------------------------ */
+
+/* Bitmap.getFilteredPixel — rt/bitmap.d:48-63 */
+DEV F3 bitmap_filtered(const float4 *texels, uint32_t width, uint32_t height, float x, float y)
+{
+    /* isInvalidPos(cast(size_t)x, cast(size_t)y): x, y are >= 0 or NaN here */
+    if (!(x < (float)width) || !(y < (float)height) || width == 0 || height == 0)
+        return mkf(1.0f, 0.0f, 0.0f); /* NamedColors.red */
+    const float fx = floorf(x), fy = floorf(y);
+    const uint32_t tx = (uint32_t)fx, ty = (uint32_t)fy;
+    const uint32_t txn = tx + 1 == width ? 0 : tx + 1;
+    const uint32_t tyn = ty + 1 == height ? 0 : ty + 1;
+    const float p = x - fx, q = y - fy;
+    const float4 c00 = texels[(size_t)ty * width + tx], c10 = texels[(size_t)ty * width + txn];
+    const float4 c01 = texels[(size_t)tyn * width + tx], c11 = texels[(size_t)tyn * width + txn];
+    const float w00 = (1.0f - p) * (1.0f - q), w10 = p * (1.0f - q), w01 = (1.0f - p) * q, w11 = p * q;
+    return mkf(c00.x, c00.y, c00.z) * w00 + mkf(c10.x, c10.y, c10.z) * w10 + mkf(c01.x, c01.y, c01.z) * w01 +
+           mkf(c11.x, c11.y, c11.z) * w11;
+}
+
+DEV F3 tex_color(const RenderParams &P, int tex, double u, double v)
+{
+    const DevTex *T = P.textures + tex;
+    const int type = T->type;
+    if (type == C2RT_TEX_CHECKER) { /* Checker.getTexColor — rt/texture.d:36-54 */
+        const double size = T->param[0];
+        const int x = d2i_x86(floor(u / size));
+        const int y = d2i_x86(floor(v / size));
+        const int white = (int)((uint32_t)x + (uint32_t)y) % 2;
+        return white ? ldf3(T->color + 3) : ldf3(T->color);
+    } else if (type == C2RT_TEX_PROCEDURE2) { /* Procedure2.getTexColor — rt/texture.d:77-86 */
+        F3 result = mkf(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            result = result + (ldf3(T->color + 3 * i) * (float)sin(u * T->param[i]) +
+                               ldf3(T->color + 9 + 3 * i) * (float)sin(v * T->param[3 + i]));
+        return result;
+    } else { /* BitmapTexture.getTexColor — rt/texture.d:116-126 */
+        const double s = (double)T->scaling;
+        u *= s;
+        v *= s;
+        u = u - floor(u);
+        v = v - floor(v);
+        const uint32_t w = T->width, hgt = T->height;
+        const float tx = (float)u * (float)w;
+        const float ty = (float)v * (float)hgt;
+        return bitmap_filtered(reinterpret_cast<const float4 *>(P.texels) + T->offset, w, hgt, tx, ty);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* shading — rt/shader.d:67-105,197-250                                  */
+/* ------------------------------------------------------------------ */
+
+template <int LEVELS>
+DEV F3 shade(const RenderParams &P, const Ctx &cx, int shader, D3 rd, const Hit &h, uint32_t &shadow_rays)
+{
+    const DevShader *S = P.shaders + shader;
+    const bool phong = S->type == C2RT_SHADER_PHONG;
+    const D3 N = dot(rd, h.n) < 0 ? h.n : -h.n; /* faceforward — rt/imported_types.d:69-73 */
+    const int tex = S->tex;
+    const F3 diffuse = tex >= 0 ? tex_color(P, tex, h.u, h.v) : ldf3(S->color);
+    F3 lightContrib = mkf(P.ambient[0], P.ambient[1], P.ambient[2]);
+    F3 specular = mkf(0, 0, 0);
+    const uint32_t nl = P.n_lights;
+    for (uint32_t l = 0; l < nl; ++l) {
+        const DevLight *L = P.lights + l;
+        F3 avgColor = mkf(0, 0, 0), avgSpecular = mkf(0, 0, 0);
+        if (L->lit) {
+            const D3 lightPos = ld3(L->pos);
+            shadow_rays += 1;
+            if (test_visibility<LEVELS>(cx, h.p + N * 1e-6, lightPos)) {
+                const F3 lightColor = ldf3(L->color);
+                const D3 lightDir = normalized(lightPos - h.p);
+                const double cosTheta = dot(lightDir, N);
+                const F3 baseLight = lightColor / (float)sqmag(h.p - lightPos);
+                if (cosTheta > 0) avgColor = avgColor + baseLight * (float)cosTheta;
+                if (phong) {
+                    /* reflect(-lightDir, N) — rt/imported_types.d:62-67 */
+                    const D3 ml = -lightDir;
+                    const D3 R = normalized(ml - N * (2 * dot(ml, N)));
+                    const double cosGamma = dot(R, -rd);
+                    if (cosGamma > 0)
+                        avgSpecular = avgSpecular + baseLight * (float)pow(cosGamma, S->exponent) * S->strength;
+                }
+            }
+        }
+        /* `/ numSamples` with numSamples == 1 (rt/light.d:56-59) is exact */
+        lightContrib = lightContrib + avgColor;
+        specular = specular + avgSpecular;
+    }
+    const F3 res = diffuse * lightContrib;
+    return phong ? res + specular : res;
+}
+
+/* ------------------------------------------------------------------ */
+/* camera — rt/camera.d:123-173                                          */
+/* ------------------------------------------------------------------ */
+
+DEV double rng_uniform(uint64_t seed, uint64_t pixel, uint32_t tap, uint32_t sample, uint32_t dim)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (1 + (((pixel * 8 + tap) * 4096 + sample) * 8 + dim));
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * 0x1p-53;
+}
+
+struct Rng { uint64_t seed, pixel; uint32_t tap, sample, dim; };
+DEV double rng_next(Rng &r) { return rng_uniform(r.seed, r.pixel, r.tap, r.sample, r.dim++); }
+
+template <bool DOF>
+DEV void screen_ray(const c2rt_camera_frame &cam, double x, double y, int offset, Rng &rng, D3 &orig, D3 &dir)
+{
+    const D3 pos = ld3(cam.pos), upLeft = ld3(cam.up_left);
+    const D3 target = upLeft + (ld3(cam.up_right) - upLeft) * (x / cam.frame_width) +
+                      (ld3(cam.down_left) - upLeft) * (y / cam.frame_height);
+    orig = pos;
+    dir = normalized(target - pos);
+    if constexpr (DOF) {
+        const D3 rightDir = ld3(cam.right_dir);
+        if (offset != 0) orig = orig + rightDir * (offset > 0 ? +cam.stereo_separation : -cam.stereo_separation);
+        if (!cam.dof) return;
+        const double cosTheta = dot(dir, ld3(cam.front_dir));
+        const double M = cam.focal_plane_dist / cosTheta;
+        const D3 T = orig + dir * M;
+        constexpr double PI = 3.14159265358979323846;
+        const double angle = rng_next(rng) * 2 * PI;
+        const double rad = sqrt(rng_next(rng));
+        double dx = sin(angle) * rad, dy = cos(angle) * rad;
+        dx *= cam.disc_multiplier;
+        dy *= cam.disc_multiplier;
+        orig = pos + rightDir * dx + ld3(cam.up_dir) * dy;
+        if (offset != 0) orig = orig + rightDir * (offset > 0 ? +cam.stereo_separation : -cam.stereo_separation);
+        dir = normalized(T - orig);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* renderer — rt/renderer.d:223-376                                      */
+/* ------------------------------------------------------------------ */
+
+struct Counters { uint32_t primary, shadow; };
+
+/* trace + raytrace_impl — rt/renderer.d:325-376 (primary rays have depth 0) */
+template <int LEVELS>
+DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt, c2rt_trace_result *probe)
+{
+    cnt.primary += 1;
+    const RayW ray = make_ray(o, d);
+    Hit best;
+    best.dist = 1e99;
+    best.p = best.n = mk(0, 0, 0);
+    best.u = best.v = 0;
+    best.g = -1;
+    int closest = -1;
+    const uint32_t nn = P.n_nodes;
+    for (uint32_t n = 0; n < nn; ++n)
+        if (node_intersect<LEVELS, kFull>(cx, P.nodes + n, ray, best)) closest = (int)n;
+    if (probe) {
+        probe->closest_node = closest;
+        probe->leaf_geom = closest >= 0 ? best.g : -1;
+        probe->p[0] = best.p.x; probe->p[1] = best.p.y; probe->p[2] = best.p.z;
+        probe->normal[0] = best.n.x; probe->normal[1] = best.n.y; probe->normal[2] = best.n.z;
+        probe->dist = best.dist; probe->u = best.u; probe->v = best.v;
+        probe->ray_orig[0] = o.x; probe->ray_orig[1] = o.y; probe->ray_orig[2] = o.z;
+        probe->ray_dir[0] = d.x; probe->ray_dir[1] = d.y; probe->ray_dir[2] = d.z;
+    }
+    if (closest < 0) return mkf(0, 0, 0); /* Environment.getEnvironment — rt/environment.d:7-10 */
+    return shade<LEVELS>(P, cx, P.nodes[closest].shader, d, best, cnt.shadow);
+}
+
+/* adjustSaturation + combineStereo — rt/color.d:10-15,77-83 */
+DEV F3 desaturate(F3 c, float amount)
+{
+    const float mid = (c.r + c.g + c.b) / 3;
+    return mkf(c.r * amount + mid * (1 - amount), c.g * amount + mid * (1 - amount), c.b * amount + mid * (1 - amount));
+}
+DEV F3 combine_stereo(F3 l, F3 r)
+{
+    l = desaturate(l, 0.25f);
+    r = desaturate(r, 0.25f);
+    return l * mkf(1, 0, 0) + r * mkf(0, 1, 1);
+}
+
+/* renderSample — rt/renderer.d:254-313 */
+template <int LEVELS, bool DOF>
+DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, uint64_t pixel, uint32_t tap,
+                     Counters &cnt, c2rt_trace_result *probe)
+{
+    Rng rng = {P.seed, pixel, tap, 0, 0};
+    D3 o, d;
+    if constexpr (!DOF) {
+        screen_ray<false>(P.cam, x, y, 0, rng, o, d);
+        return raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+    } else {
+        const bool stereo = P.cam.stereo_separation != 0;
+        if (P.cam.dof) {
+            F3 average = mkf(0, 0, 0);
+            const uint32_t ns = P.cam.num_samples;
+            for (uint32_t i = 0; i < ns; ++i) {
+                rng.sample = i;
+                rng.dim = 0;
+                double jx = rng_next(rng), jy = rng_next(rng);
+                if (!stereo) {
+                    screen_ray<true>(P.cam, x + jx * 1, y + jy * 1, 0, rng, o, d);
+                    average = average + raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+                } else {
+                    screen_ray<true>(P.cam, x + jx * 1, y + jy * 1, -1, rng, o, d);
+                    const F3 l = raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+                    jx = rng_next(rng), jy = rng_next(rng);
+                    screen_ray<true>(P.cam, x + jx * 1, y + jy * 1, +1, rng, o, d);
+                    const F3 r = raytrace<LEVELS>(P, cx, o, d, cnt, nullptr);
+                    average = average + combine_stereo(l, r);
+                }
+            }
+            return average / (float)ns;
+        }
+        if (!stereo) {
+            screen_ray<true>(P.cam, x, y, 0, rng, o, d);
+            return raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+        }
+        screen_ray<true>(P.cam, x, y, -1, rng, o, d);
+        const F3 l = raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+        screen_ray<true>(P.cam, x, y, +1, rng, o, d);
+        const F3 r = raytrace<LEVELS>(P, cx, o, d, cnt, nullptr);
+        return combine_stereo(l, r);
+    }
+}
+
+/* AA kernel — rt/renderer.d:235-242 */
+__constant__ double k_aa_x[5] = {0.0, 0.3, 0.6, 0.0, 0.6};
+__constant__ double k_aa_y[5] = {0.0, 0.3, 0.0, 0.6, 0.6};
+
+/*
+ * Frame kernel: Renderer.renderRT passes 2 and 3b (rt/renderer.d:133-142,
+ * 183-186) fused — all taps of a pixel are accumulated in registers in the
+ * reference's order and the pixel is written once (12 B of HBM traffic per
+ * pixel).  One workgroup = one wavefront = one 8x8 tile.
+ */
+template <int LEVELS, bool DOF>
+__global__ void __launch_bounds__(kWave) C2RT_OCC render_kernel(const RenderParams P)
+{
+    extern __shared__ __align__(16) char lds[];
+    const int lane = threadIdx.x;
+
+    /* XCD-aware block -> tile: blocks b and b+8 share an XCD (round-robin
+     * dispatch), so XCD x gets tile rows x, x+8, x+16, ... and walks them
+     * left to right. */
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u, j = b >> 3;
+    const uint32_t trow = (j / P.tiles_x) * 8u + xcd, tcol = j % P.tiles_x;
+    if (trow >= P.tiles_y) return;
+
+    const uint32_t x = tcol * kTileW + (lane & 7);
+    const uint32_t lr = trow * kTileH + (lane >> 3); /* local row */
+    if (x >= P.width || lr >= P.local_rows) return;
+
+    /* local row -> frame row under interleaved strips */
+    uint32_t y = lr;
+    if (P.strip_world > 1) {
+        const uint32_t sh = P.strip_height;
+        y = ((lr / sh) * P.strip_world + P.strip_rank) * sh + lr % sh;
+    }
+
+    Ctx cx;
+    cx.geoms = P.geoms;
+    cx.nodes = P.nodes;
+    cx.n_nodes = P.n_nodes;
+    cx.lds = lds;
+    cx.lane = lane;
+    Counters cnt = {0, 0};
+    const uint64_t pixel = (uint64_t)y * P.width + x;
+    const uint32_t ntaps = P.taps;
+
+    /* renderPixelNoAA — rt/renderer.d:223-228; renderPixelAA — :233-251.
+     * Tap 0 has offset (0, 0): x + 0.0 == x, and 0 + c == c for the first
+     * sample, so one loop covers both passes. */
+    F3 accum = mkf(0, 0, 0);
+#pragma unroll 1
+    for (uint32_t s = 0; s < ntaps; ++s) {
+        const F3 c = render_sample<LEVELS, DOF>(P, cx, (double)x + k_aa_x[s], (double)y + k_aa_y[s], pixel, s, cnt, nullptr);
+        accum = s == 0 ? c : accum + c;
+    }
+    if (ntaps > 1) accum = accum / (float)ntaps; /* `accum / 5`: Color / float */
+
+    float *px = P.out + ((size_t)lr * P.width + x) * 3;
+    px[0] = accum.r;
+    px[1] = accum.g;
+    px[2] = accum.b;
+
+    if (P.ray_counters) {
+        atomicAdd(P.ray_counters + 0, (unsigned long long)cnt.primary);
+        atomicAdd(P.ray_counters + 1, (unsigned long long)cnt.shadow);
+    }
+}
+
+/* renderPixel — rt/renderer.d:46-57: one lane, one sample, full trace result */
+template <int LEVELS, bool DOF>
+__global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
+{
+    extern __shared__ __align__(16) char lds[];
+    if (threadIdx.x != 0) return;
+    Ctx cx;
+    cx.geoms = P.geoms;
+    cx.nodes = P.nodes;
+    cx.n_nodes = P.n_nodes;
+    cx.lds = lds;
+    cx.lane = 0;
+    Counters cnt = {0, 0};
+    const uint64_t pixel = (uint64_t)P.probe_y * P.width + (uint64_t)P.probe_x;
+    const F3 c = render_sample<LEVELS, DOF>(P, cx, (double)P.probe_x, (double)P.probe_y, pixel, 0, cnt, P.probe_out);
+    P.probe_out->color[0] = c.r;
+    P.probe_out->color[1] = c.g;
+    P.probe_out->color[2] = c.b;
+}
+
+#if C2RT_UNIT == 5
+/* Rank-major strip buffers, each `rows_pad` rows (what a gather of equal-sized
+ * per-rank buffers leaves on rank 0) -> full frame.  blockIdx.y
+ * = frame row; float4 copies when a row is a multiple of 16 B. */
+__global__ void deinterleave_kernel(const float *__restrict__ gathered, float *__restrict__ frame,
+                                    uint32_t row_floats, uint32_t strip_height, uint32_t world, uint32_t rows_pad)
+{
+    const uint32_t y = blockIdx.y;
+    const uint32_t strip = y / strip_height;
+    const uint32_t rank = strip % world;
+    const uint32_t lr = (strip / world) * strip_height + y % strip_height;
+    const float *src = gathered + ((size_t)rank * rows_pad + lr) * (size_t)row_floats;
+    float *dst = frame + (size_t)y * row_floats;
+    if ((row_floats & 3u) == 0) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < row_floats / 4; i += gridDim.x * blockDim.x) d4[i] = s4[i];
+    } else {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < row_floats; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    }
+}
+
+/* Color.toRGB32 via convertTo8bit_sRGB_Cached — rt/color.d:154-162,209-214 */
+__global__ void encode_rgb32_kernel(const float *__restrict__ frame, uint32_t *__restrict__ out, uint64_t n,
+                                    const uint8_t *__restrict__ lut)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t ch[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = frame[3 * i + c];
+            ch[c] = !(x > 0) ? 0u : (x >= 1 ? 255u : (uint32_t)lut[(int)(x * 4096.0f)]);
+        }
+        out[i] = ch[2] | (ch[1] << 8) | (ch[0] << 16);
+    }
+}
+#endif /* C2RT_UNIT == 5 */
+
+} // namespace
+
+/*
+ * Instantiation is split over translation units so that the (slow) device
+ * compiles run in parallel: the Makefile builds this file once per
+ * C2RT_UNIT = 0..4 (the frame kernel for that many CSG nesting levels) and
+ * once with C2RT_UNIT = 5 (probe, de-interleave, encode, dispatcher).
+ */
+#ifndef C2RT_UNIT
+#error "compile with -DC2RT_UNIT=0..5 (see Makefile)"
+#endif
+
+#if C2RT_UNIT >= 0 && C2RT_UNIT <= C2RT_MAX_CSG_DEPTH
+
+template <>
+int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t tiles_y_pad = (p.tiles_y + 7u) / 8u * 8u;
+    const dim3 grid(p.tiles_x * tiles_y_pad), block(kWave);
+    const size_t lds = (size_t)C2RT_UNIT * kCsgLdsPerLevel;
+    if (dof_or_stereo)
+        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, true>), grid, block, lds, s, p);
+    else
+        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, false>), grid, block, lds, s, p);
+    return (int)hipGetLastError();
+}
+
+#else /* C2RT_UNIT == 5 */
+
+int launch_render(const RenderParams &p, const KernelVariant &v, void *stream)
+{
+    switch (v.csg_levels) {
+    case 0: return launch_render_level<0>(p, v.dof_or_stereo, stream);
+    case 1: return launch_render_level<1>(p, v.dof_or_stereo, stream);
+    case 2: return launch_render_level<2>(p, v.dof_or_stereo, stream);
+    case 3: return launch_render_level<3>(p, v.dof_or_stereo, stream);
+    case 4: return launch_render_level<4>(p, v.dof_or_stereo, stream);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
+/* the probe is not a hot path: one instance that handles every scene */
+int launch_probe(const RenderParams &p, const KernelVariant &, void *stream)
+{
+    const size_t lds = (size_t)C2RT_MAX_CSG_DEPTH * kCsgLdsPerLevel;
+    hipLaunchKernelGGL((probe_kernel<C2RT_MAX_CSG_DEPTH, true>), dim3(1), dim3(kWave), lds,
+                       static_cast<hipStream_t>(stream), p);
+    return (int)hipGetLastError();
+}
+
+int launch_deinterleave(const float *gathered, float *frame, uint32_t width, uint32_t height,
+                        uint32_t strip_height, uint32_t world, uint32_t rows_pad, void *stream)
+{
+    const uint32_t row_floats = width * 3u;
+    const uint32_t per_row = (row_floats & 3u) == 0 ? row_floats / 4 : row_floats;
+    const dim3 block(256), grid((per_row + 255) / 256 > 16 ? 16 : (per_row + 255) / 256, height);
+    hipLaunchKernelGGL(deinterleave_kernel, grid, block, 0, static_cast<hipStream_t>(stream), gathered, frame,
+                       row_floats, strip_height, world, rows_pad);
+    return (int)hipGetLastError();
+}
+
+int launch_encode_rgb32(const float *frame, uint32_t *out, uint64_t n_pixels, const uint8_t *lut_dev, void *stream)
+{
+    const uint64_t blocks = (n_pixels + 255) / 256;
+    const dim3 block(256), grid((uint32_t)(blocks > 4096 ? 4096 : (blocks ? blocks : 1)));
+    hipLaunchKernelGGL(encode_rgb32_kernel, grid, block, 0, static_cast<hipStream_t>(stream), frame, out, n_pixels,
+                       lut_dev);
+    return (int)hipGetLastError();
+}
+
+#endif
+
+} // namespace c2rt

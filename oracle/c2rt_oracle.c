@@ -1,0 +1,1271 @@
+/*
+ * c2rt_oracle.c — CPU restatement of Chess2RT's render hot path (plain C).
+ *
+ * TEST INFRASTRUCTURE ONLY (see c2rt_oracle.h).  Parity status: pinned
+ * against the reference's BMP known-answer unittests; the ray/shade path is
+ * "parity unpinned" by reference tests (there are none) and
+ * rests on this line-by-line restatement plus hand-derived anchors.
+ *
+ * Every function names the reference lines it follows
+ * (paths relative to /root/reference/source/).  Arithmetic is written in the
+ * reference's evaluation order; compile with -ffp-contract=off.
+ *
+ * gfm:math 7.0.8 (dub.selections.json:6) is not vendored in the reference;
+ * the helpers in the "gfm" block restate its published algorithms:
+ *   vec3d  + - * / (component-wise), dot (sum = 0; sum += a_i*b_i),
+ *   cross, squaredMagnitude, magnitude = sqrt(squaredMagnitude),
+ *   normalize: v *= 1 / magnitude;
+ *   mat3d  row-major c[i][j], operator* (sum = 0; sum += a[i][k]*b[k][j]),
+ *   inverse by cofactors * (1/det), transposed, rotateX/Y/Z via
+ *   rotateAxis!(i,j): c[i][i]=cos, c[i][j]=-sin, c[j][i]=sin, c[j][j]=cos;
+ *   radians(x) = x * (PI/180).
+ */
+#include "c2rt_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+/* ===================================================================== */
+/* gfm:math restatement                                                   */
+/* ===================================================================== */
+
+typedef struct { double x, y, z; } V3;
+typedef struct { double c[3][3]; } M3;
+
+static inline V3 v3(double x, double y, double z) { V3 r = {x, y, z}; return r; }
+static inline V3 v3p(const double *p) { return v3(p[0], p[1], p[2]); }
+static inline void v3store(double *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+static inline V3 vadd(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 vmul(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline V3 vneg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+static inline double vdot(V3 a, V3 b)
+{
+    double sum = 0;
+    sum += a.x * b.x;
+    sum += a.y * b.y;
+    sum += a.z * b.z;
+    return sum;
+}
+static inline V3 vcross(V3 a, V3 b)
+{
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline double vsqmag(V3 a)
+{
+    double s = 0;
+    s += a.x * a.x;
+    s += a.y * a.y;
+    s += a.z * a.z;
+    return s;
+}
+static inline double vmag(V3 a) { return sqrt(vsqmag(a)); }
+static inline V3 vnormalized(V3 a)
+{
+    double inv = 1 / vmag(a);
+    return v3(a.x * inv, a.y * inv, a.z * inv);
+}
+static inline double vget(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+static inline void vset(V3 *v, int i, double s)
+{
+    if (i == 0) v->x = s; else if (i == 1) v->y = s; else v->z = s;
+}
+
+static M3 m_identity(void)
+{
+    M3 m;
+    memset(&m, 0, sizeof m);
+    m.c[0][0] = m.c[1][1] = m.c[2][2] = 1.0;
+    return m;
+}
+static M3 m_mul(M3 a, M3 b)
+{
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double sum = 0;
+            for (int k = 0; k < 3; ++k) sum += a.c[i][k] * b.c[k][j];
+            r.c[i][j] = sum;
+        }
+    return r;
+}
+static M3 m_inverse(M3 m)
+{
+    const double (*c)[3] = m.c;
+    double det = c[0][0] * (c[1][1] * c[2][2] - c[2][1] * c[1][2])
+               - c[0][1] * (c[1][0] * c[2][2] - c[1][2] * c[2][0])
+               + c[0][2] * (c[1][0] * c[2][1] - c[1][1] * c[2][0]);
+    double invDet = 1 / det;
+    M3 r;
+    r.c[0][0] =  (c[1][1] * c[2][2] - c[2][1] * c[1][2]) * invDet;
+    r.c[0][1] = -(c[0][1] * c[2][2] - c[0][2] * c[2][1]) * invDet;
+    r.c[0][2] =  (c[0][1] * c[1][2] - c[0][2] * c[1][1]) * invDet;
+    r.c[1][0] = -(c[1][0] * c[2][2] - c[1][2] * c[2][0]) * invDet;
+    r.c[1][1] =  (c[0][0] * c[2][2] - c[0][2] * c[2][0]) * invDet;
+    r.c[1][2] = -(c[0][0] * c[1][2] - c[1][0] * c[0][2]) * invDet;
+    r.c[2][0] =  (c[1][0] * c[2][1] - c[2][0] * c[1][1]) * invDet;
+    r.c[2][1] = -(c[0][0] * c[2][1] - c[2][0] * c[0][1]) * invDet;
+    r.c[2][2] =  (c[0][0] * c[1][1] - c[1][0] * c[0][1]) * invDet;
+    return r;
+}
+static M3 m_transposed(M3 m)
+{
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.c[i][j] = m.c[j][i];
+    return r;
+}
+static M3 m_rotate_axis(int i, int j, double angle)
+{
+    M3 r = m_identity();
+    double cosa = cos(angle), sina = sin(angle);
+    r.c[i][i] = cosa;
+    r.c[i][j] = -sina;
+    r.c[j][i] = sina;
+    r.c[j][j] = cosa;
+    return r;
+}
+static M3 m_rotate_x(double a) { return m_rotate_axis(1, 2, a); }
+static M3 m_rotate_y(double a) { return m_rotate_axis(2, 0, a); }
+static M3 m_rotate_z(double a) { return m_rotate_axis(0, 1, a); }
+
+#define ORC_PI 3.14159265358979323846
+/* cast(double)(PI / 180) with PI an 80-bit real: nearest double of pi/180 */
+static inline double radians_(double x) { return x * 0x1.1df46a2529d39p-6; }
+
+/* ===================================================================== */
+/* rt/imported_types.d                                                    */
+/* ===================================================================== */
+
+/* mul(v, M): row vector x matrix — rt/imported_types.d:13-20 */
+static inline V3 mul_vm(V3 v, const double *m /* 9, row-major */)
+{
+    return v3(v.x * m[0] + v.y * m[3] + v.z * m[6],
+              v.x * m[1] + v.y * m[4] + v.z * m[7],
+              v.x * m[2] + v.y * m[5] + v.z * m[8]);
+}
+static inline V3 mul_vM3(V3 v, M3 m) { return mul_vm(v, &m.c[0][0]); }
+
+/* project / unproject — rt/imported_types.d:44-60 */
+static inline V3 project_(V3 v, int a, int b, int c)
+{
+    V3 r = v3(NAN, NAN, NAN);
+    vset(&r, a, v.x);
+    vset(&r, b, v.y);
+    vset(&r, c, v.z);
+    return r;
+}
+static inline V3 unproject_(V3 v, int a, int b, int c)
+{
+    return v3(vget(v, a), vget(v, b), vget(v, c));
+}
+/* reflect — rt/imported_types.d:62-67 */
+static inline V3 reflect_(V3 ray, V3 norm)
+{
+    V3 r = vsub(ray, vmul(norm, 2 * vdot(ray, norm)));
+    return vnormalized(r);
+}
+/* faceforward — rt/imported_types.d:69-73 */
+static inline V3 faceforward_(V3 ray, V3 norm)
+{
+    if (vdot(ray, norm) < 0) return norm;
+    return vneg(norm);
+}
+
+/* ===================================================================== */
+/* rt/color.d                                                             */
+/* ===================================================================== */
+
+typedef struct { float r, g, b; } Col;
+static inline Col col(float r, float g, float b) { Col c = {r, g, b}; return c; }
+static inline Col colp(const float *p) { return col(p[0], p[1], p[2]); }
+/* opBinary + - * (Color) — rt/color.d:122-126 */
+static inline Col cadd(Col a, Col b) { return col(a.r + b.r, a.g + b.g, a.b + b.b); }
+static inline Col cmulc(Col a, Col b) { return col(a.r * b.r, a.g * b.g, a.b * b.b); }
+/* opBinary * / (float) — rt/color.d:128-132; double arguments narrow first */
+static inline Col cmulf(Col a, float f) { return col(a.r * f, a.g * f, a.b * f); }
+static inline Col cdivf(Col a, float f) { return col(a.r / f, a.g / f, a.b / f); }
+/* intensity — rt/color.d:141-144 */
+static inline float cintensity(Col a) { return (a.r + a.g + a.b) / 3; }
+/* adjustSaturation — rt/color.d:77-83 */
+static inline Col cadjust_saturation(Col c, float amount)
+{
+    float mid = cintensity(c);
+    return col(c.r * amount + mid * (1 - amount), c.g * amount + mid * (1 - amount),
+               c.b * amount + mid * (1 - amount));
+}
+/* combineStereo — rt/color.d:10-15 */
+static inline Col combine_stereo(Col left, Col right)
+{
+    left = cadjust_saturation(left, 0.25f);
+    right = cadjust_saturation(right, 0.25f);
+    return cadd(cmulc(left, col(1, 0, 0)), cmulc(right, col(0, 1, 1)));
+}
+
+/* x86-64 cvttsd2si semantics for cast(int)/cast(size_t) of out-of-range or
+ * NaN doubles/floats ("integer indefinite"), which is what the reference
+ * binary executes. */
+static inline int32_t d2i_x86(double d)
+{
+    if (d > -2147483649.0 && d < 2147483648.0) return (int32_t)d;
+    return INT32_MIN;
+}
+static inline uint64_t f2u64_x86(float f)
+{
+    /* cast(size_t) float: cvttss2si r64 (signed); out of range/NaN -> 1<<63 */
+    if (f > -9223373136366403584.0f && f < 9223372036854775808.0f)
+        return (uint64_t)(int64_t)f;
+    return (uint64_t)1 << 63;
+}
+
+/* roundToByte / convertTo8bit_sRGB(_Cached) — rt/color.d:181-228 */
+static uint8_t g_srgb_lut[4097];
+static pthread_once_t g_srgb_once = PTHREAD_ONCE_INIT;
+static uint8_t round_to_byte(float x) { return (uint8_t)(int)floor(x * 255.0f); }
+static uint8_t convert_to_8bit_srgb(float x)
+{
+    if (x <= 0) return 0;
+    if (x >= 1) return 255;
+    if (x <= 0.0031308f)
+        x = x * 12.02f; /* sic: rt/color.d:200-201 */
+    else
+        x = (float)(1.055 * pow((double)x, 1 / 2.4) - 0.055);
+    return round_to_byte(x);
+}
+static void srgb_lut_init(void)
+{
+    for (int i = 0; i < 4097; ++i) g_srgb_lut[i] = convert_to_8bit_srgb(i / 4096.0f);
+}
+static uint8_t convert_to_8bit_srgb_cached(float x)
+{
+    if (x <= 0) return 0;
+    if (x >= 1) return 255;
+    return g_srgb_lut[(int)(x * 4096.0f)];
+}
+uint32_t orc_color_to_rgb32(const float rgb[3])
+{
+    pthread_once(&g_srgb_once, srgb_lut_init);
+    /* a NaN channel fails both range tests and indexes with
+     * cast(int)NaN = INT_MIN in the reference (out of bounds); map it to 0 */
+    uint32_t ch[3];
+    for (int i = 0; i < 3; ++i) ch[i] = (rgb[i] != rgb[i]) ? 0 : convert_to_8bit_srgb_cached(rgb[i]);
+    return (ch[2] << 0) | (ch[1] << 8) | (ch[0] << 16);
+}
+
+/* ===================================================================== */
+/* rt/ray.d, rt/intersectable.d                                            */
+/* ===================================================================== */
+
+typedef struct { V3 orig, dir; int depth; } Ray;
+
+typedef struct {               /* IntersectionData — rt/intersectable.d:6-33 */
+    V3 p, normal;
+    double dist, u, v;
+    int32_t g;
+    V3 dNdx, dNdy;
+} ID;
+
+static ID id_init(void)
+{
+    ID d;
+    d.p = d.normal = d.dNdx = d.dNdy = v3(NAN, NAN, NAN);
+    d.dist = d.u = d.v = NAN;
+    d.g = -1;
+    return d;
+}
+
+/* Ray project — rt/ray.d:64-70 */
+static inline Ray ray_project(Ray r, int a, int b, int c)
+{
+    r.orig = project_(r.orig, a, b, c);
+    r.dir = project_(r.dir, a, b, c);
+    return r;
+}
+
+/* ===================================================================== */
+/* util/array.d                                                           */
+/* ===================================================================== */
+
+typedef struct { ID *storage; size_t cap, n; } IDArray; /* MyArray!ID — util/array.d:3-64 */
+
+static void ida_push(IDArray *a, const ID *v)
+{
+    if (a->n >= a->cap) {
+        size_t nc = a->cap > 0 ? a->cap * 2 : 16; /* defaultInitialCapacity */
+        a->storage = (ID *)realloc(a->storage, nc * sizeof(ID));
+        a->cap = nc;
+    }
+    a->storage[a->n++] = *v;
+}
+static void ida_free(IDArray *a) { free(a->storage); a->storage = NULL; a->cap = a->n = 0; }
+
+/* sort (shell sort) — util/array.d:95-111; compare = opCmp on dist,
+ * rt/intersectable.d:27-32.  The foreach index is taken by ref and rewound
+ * by the inner while. */
+static void shell_sort_ids(ID *arr, size_t n)
+{
+    size_t inc = n / 2;
+    while (inc) {
+        for (size_t i = 0; i < n; ++i) {
+            ID elem = arr[i];
+            while (i >= inc && arr[i - inc].dist > elem.dist) {
+                arr[i] = arr[i - inc];
+                i -= inc;
+            }
+            arr[i] = elem;
+        }
+        inc = (inc == 2) ? 1 : (size_t)(int)(inc * 5.0 / 11);
+    }
+}
+
+/* ===================================================================== */
+/* rt/geometry.d                                                          */
+/* ===================================================================== */
+
+typedef const c2rt_scene_desc Scene;
+
+static int geom_intersect(Scene *s, int32_t g, Ray ray, ID *data);
+static int geom_is_inside(Scene *s, int32_t g, V3 p);
+
+/* Plane.intersect — rt/geometry.d:30-59 */
+static int plane_intersect(Scene *s, int32_t g, Ray ray, ID *data)
+{
+    double y = s->geom_param[4 * g + 0], limit = s->geom_param[4 * g + 1];
+    if ((ray.orig.y > y && ray.dir.y > -1e-9) || (ray.orig.y < y && ray.dir.y < 1e-9))
+        return 0;
+    double yDiff = ray.dir.y;
+    double wantYDiff = ray.orig.y - y;
+    double mult = wantYDiff / -yDiff;
+    if (mult > data->dist) return 0;
+    V3 p = vadd(ray.orig, vmul(ray.dir, mult));
+    if (fabs(p.x) > limit || fabs(p.z) > limit) return 0;
+    data->p = p;
+    data->dist = mult;
+    data->normal = v3(0, 1, 0);
+    data->dNdx = v3(1, 0, 0);
+    data->dNdy = v3(0, 0, 1);
+    data->u = data->p.x;
+    data->v = data->p.z;
+    data->g = g;
+    return 1;
+}
+
+/* Sphere.intersect — rt/geometry.d:92-125 */
+static int sphere_intersect(Scene *s, int32_t g, Ray ray, ID *info)
+{
+    V3 center = v3p(&s->geom_param[4 * g]);
+    double R = s->geom_param[4 * g + 3];
+    V3 H = vsub(ray.orig, center);
+    double A = vsqmag(ray.dir);
+    double B = 2 * vdot(H, ray.dir);
+    double C = vsqmag(H) - R * R;
+    double Dscr = B * B - 4 * A * C;
+    if (Dscr < 0) return 0;
+    double x1 = (-B + sqrt(Dscr)) / (2 * A);
+    double x2 = (-B - sqrt(Dscr)) / (2 * A);
+    double sol = x2;
+    if (sol < 0) sol = x1;
+    if (sol < 0) return 0;
+    if (sol > info->dist) return 0;
+    info->dist = sol;
+    info->p = vadd(ray.orig, vmul(ray.dir, sol));
+    info->normal = vsub(info->p, center);
+    info->normal = vnormalized(info->normal);
+    double angle = atan2(info->p.z - center.z, info->p.x - center.x);
+    info->u = (ORC_PI + angle) / (2 * ORC_PI);
+    info->v = 1.0 - (ORC_PI / 2 + asin((info->p.y - center.y) / R)) / ORC_PI;
+    info->dNdx = v3(cos(angle + ORC_PI / 2), 0, sin(angle + ORC_PI / 2));
+    info->dNdy = vcross(info->dNdx, info->normal);
+    info->g = g;
+    return 1;
+}
+
+/* Sphere.isInside — rt/geometry.d:127-130 */
+static int sphere_is_inside(Scene *s, int32_t g, V3 p)
+{
+    V3 center = v3p(&s->geom_param[4 * g]);
+    double R = s->geom_param[4 * g + 3];
+    return vsqmag(vsub(center, p)) < R * R;
+}
+
+/* Cube.intersectCubeSide — rt/geometry.d:198-235 */
+static int cube_side(double cubeSide, Ray ray, V3 center, ID *data)
+{
+    if (fabs(ray.dir.y) < 1e-9) return 0;
+    double halfSide = cubeSide * 0.5;
+    int found = 0;
+    for (int side = -1; side <= 1; side += 2) {
+        double yDiff = ray.dir.y;
+        double wantYDiff = ray.orig.y - (center.y + side * halfSide);
+        double mult = wantYDiff / -yDiff;
+        if (mult < 0) continue;
+        if (mult > data->dist) continue;
+        V3 p = vadd(ray.orig, vmul(ray.dir, mult));
+        if (p.x < center.x - halfSide || p.x > center.x + halfSide ||
+            p.z < center.z - halfSide || p.z > center.z + halfSide)
+            continue;
+        data->p = vadd(ray.orig, vmul(ray.dir, mult));
+        data->dist = mult;
+        data->normal = v3(0, side, 0);
+        data->dNdx = v3(1, 0, 0);
+        data->dNdy = v3(0, 0, side);
+        data->u = data->p.x - center.x;
+        data->v = data->p.z - center.z;
+        found = 1;
+    }
+    return found;
+}
+
+/* Cube.intersect — rt/geometry.d:172-196 */
+static int cube_intersect(Scene *s, int32_t g, Ray ray, ID *data)
+{
+    V3 center = v3p(&s->geom_param[4 * g]);
+    double side = s->geom_param[4 * g + 3];
+    int found = cube_side(side, ray, center, data);
+    if (cube_side(side, ray_project(ray, 1, 0, 2), project_(center, 1, 0, 2), data)) {
+        found = 1;
+        data->normal = unproject_(data->normal, 1, 0, 2);
+        data->p = unproject_(data->p, 1, 0, 2);
+    }
+    if (cube_side(side, ray_project(ray, 0, 2, 1), project_(center, 0, 2, 1), data)) {
+        found = 1;
+        data->normal = unproject_(data->normal, 0, 2, 1);
+        data->p = unproject_(data->p, 0, 2, 1);
+    }
+    if (found) data->g = g;
+    return found;
+}
+
+/* Cube.isInside — rt/geometry.d:165-170 */
+static int cube_is_inside(Scene *s, int32_t g, V3 p)
+{
+    V3 center = v3p(&s->geom_param[4 * g]);
+    double side = s->geom_param[4 * g + 3];
+    return fabs(p.x - center.x) <= side * 0.5 && fabs(p.y - center.y) <= side * 0.5 &&
+           fabs(p.z - center.z) <= side * 0.5;
+}
+
+/* boolOp — rt/geometry.d:361-364,371-374,399-402 */
+static int csg_bool_op(int type, int inL, int inR)
+{
+    switch (type) {
+    case C2RT_GEOM_CSG_UNION: return inL || inR;
+    case C2RT_GEOM_CSG_INTER: return inL && inR;
+    default: return inL && !inR;
+    }
+}
+
+/* CsgOp.findAllIntersections — rt/geometry.d:271-290 */
+static void csg_find_all(Scene *s, int32_t geom, Ray ray, IDArray *l)
+{
+    double currentLength = 0;
+    for (;;) {
+        ID temp = id_init();
+        temp.dist = 1e99;
+        if (!geom_intersect(s, geom, ray, &temp)) break;
+        temp.dist += currentLength;
+        currentLength = temp.dist;
+        ray.orig = vadd(temp.p, vmul(ray.dir, 1e-6));
+        ida_push(l, &temp);
+    }
+}
+
+/* CsgOp.intersect — rt/geometry.d:292-332 */
+static int csg_intersect_base(Scene *s, int32_t g, Ray ray, ID *data)
+{
+    int32_t left = s->geom_child[2 * g + 0], right = s->geom_child[2 * g + 1];
+    int type = s->geom_type[g];
+    IDArray leftData = {0}, rightData = {0}, allData = {0};
+    csg_find_all(s, left, ray, &leftData);
+    csg_find_all(s, right, ray, &rightData);
+    for (size_t i = 0; i < leftData.n; ++i) ida_push(&allData, &leftData.storage[i]);
+    for (size_t i = 0; i < rightData.n; ++i) ida_push(&allData, &rightData.storage[i]);
+    shell_sort_ids(allData.storage, allData.n);
+    int inL = leftData.n % 2 == 1;
+    int inR = rightData.n % 2 == 1;
+    int result = 0;
+    for (size_t i = 0; i < allData.n; ++i) {
+        const ID *current = &allData.storage[i];
+        if (current->g == left) /* `current.g is left`: leaf identity */
+            inL = !inL;
+        else
+            inR = !inR;
+        if (csg_bool_op(type, inL, inR)) {
+            if (current->dist > data->dist) { result = 0; break; }
+            *data = *current;
+            result = 1;
+            break;
+        }
+    }
+    ida_free(&leftData);
+    ida_free(&rightData);
+    ida_free(&allData);
+    return result;
+}
+
+/* CsgDiff.intersect — rt/geometry.d:382-397 */
+static int csg_diff_intersect(Scene *s, int32_t g, Ray ray, ID *data)
+{
+    if (!csg_intersect_base(s, g, ray, data)) return 0;
+    int32_t right = s->geom_child[2 * g + 1];
+    if (geom_is_inside(s, right, vsub(data->p, vmul(ray.dir, 1e-6))) !=
+        geom_is_inside(s, right, vadd(data->p, vmul(ray.dir, 1e-6))))
+        data->normal = vneg(data->normal);
+    return 1;
+}
+
+static int geom_intersect(Scene *s, int32_t g, Ray ray, ID *data)
+{
+    switch (s->geom_type[g]) {
+    case C2RT_GEOM_PLANE: return plane_intersect(s, g, ray, data);
+    case C2RT_GEOM_SPHERE: return sphere_intersect(s, g, ray, data);
+    case C2RT_GEOM_CUBE: return cube_intersect(s, g, ray, data);
+    case C2RT_GEOM_CSG_DIFF: return csg_diff_intersect(s, g, ray, data);
+    default: return csg_intersect_base(s, g, ray, data);
+    }
+}
+
+/* isInside — rt/geometry.d:25-28,127-130,165-170,334-337 */
+static int geom_is_inside(Scene *s, int32_t g, V3 p)
+{
+    switch (s->geom_type[g]) {
+    case C2RT_GEOM_PLANE: return 0;
+    case C2RT_GEOM_SPHERE: return sphere_is_inside(s, g, p);
+    case C2RT_GEOM_CUBE: return cube_is_inside(s, g, p);
+    default: {
+        int a = geom_is_inside(s, s->geom_child[2 * g + 0], p);
+        int b = geom_is_inside(s, s->geom_child[2 * g + 1], p);
+        return csg_bool_op(s->geom_type[g], a, b);
+    }
+    }
+}
+
+/* ===================================================================== */
+/* rt/transform.d, rt/node.d                                              */
+/* ===================================================================== */
+
+#define T_M(t) ((t) + 0)
+#define T_INV(t) ((t) + 9)
+#define T_TINV(t) ((t) + 18)
+#define T_OFF(t) ((t) + 27)
+
+/* Node.intersect — rt/node.d:23-49 (Transform helpers rt/transform.d:57-86) */
+static int node_intersect(Scene *s, int32_t n, Ray ray, ID *data)
+{
+    const double *t = &s->node_transform[30 * (size_t)n];
+    Ray rc;
+    rc.orig = mul_vm(vsub(ray.orig, v3p(T_OFF(t))), T_INV(t)); /* undoPoint */
+    rc.dir = mul_vm(ray.dir, T_INV(t));                         /* undoDirection */
+    rc.depth = ray.depth;
+    double oldDist = data->dist;
+    double rayDirLength = vmag(rc.dir);
+    data->dist *= rayDirLength;
+    rc.dir = vnormalized(rc.dir);
+    if (!geom_intersect(s, s->node_geom[n], rc, data)) {
+        data->dist = oldDist;
+        return 0;
+    }
+    data->normal = vnormalized(mul_vm(data->normal, T_TINV(t)));
+    data->dNdx = vnormalized(mul_vm(data->dNdx, T_M(t)));
+    data->dNdy = vnormalized(mul_vm(data->dNdy, T_M(t)));
+    data->p = vadd(mul_vm(data->p, T_M(t)), v3p(T_OFF(t)));
+    data->dist /= rayDirLength;
+    return 1;
+}
+
+/* ===================================================================== */
+/* rt/scene.d                                                             */
+/* ===================================================================== */
+
+typedef struct { uint64_t primary, shadow; } Counters;
+
+/* Scene.testVisibility — rt/scene.d:62-78 */
+static int test_visibility(Scene *s, V3 from, V3 to, Counters *cnt)
+{
+    Ray ray;
+    ray.orig = from;
+    ray.dir = vsub(to, from);
+    ray.dir = vnormalized(ray.dir);
+    ray.depth = 0;
+    ID temp = id_init();
+    temp.dist = vmag(vsub(to, from));
+    if (cnt) cnt->shadow++;
+    for (uint32_t n = 0; n < s->n_nodes; ++n)
+        if (node_intersect(s, (int32_t)n, ray, &temp)) return 0;
+    return 1;
+}
+
+/* ===================================================================== */
+/* rt/texture.d, rt/bitmap.d                                              */
+/* ===================================================================== */
+
+/* Bitmap.getFilteredPixel — rt/bitmap.d:48-63 */
+static Col bitmap_filtered_pixel(Scene *s, int32_t tex, float x, float y)
+{
+    uint64_t width = s->tex_width[tex], height = s->tex_height[tex];
+    const float *px = s->texels + 3 * s->tex_offset[tex];
+    uint64_t cx = f2u64_x86(x), cy = f2u64_x86(y);
+    if (width * height == 0 || cx >= width || cy >= height) return col(1, 0, 0); /* NamedColors.red */
+    uint64_t tx = f2u64_x86(floorf(x));
+    uint64_t ty = f2u64_x86(floorf(y));
+    uint64_t tx_next = (tx + 1) % width;
+    uint64_t ty_next = (ty + 1) % height;
+    float p = x - (float)tx;
+    float q = y - (float)ty;
+#define TEXEL(X, Y) colp(px + 3 * ((Y) * width + (X)))
+    Col r = cmulf(TEXEL(tx, ty), (1.0f - p) * (1.0f - q));
+    r = cadd(r, cmulf(TEXEL(tx_next, ty), p * (1.0f - q)));
+    r = cadd(r, cmulf(TEXEL(tx, ty_next), (1.0f - p) * q));
+    r = cadd(r, cmulf(TEXEL(tx_next, ty_next), p * q));
+#undef TEXEL
+    return r;
+}
+
+static Col tex_color(Scene *s, int32_t tex, double u, double v)
+{
+    switch (s->tex_type[tex]) {
+    case C2RT_TEX_CHECKER: { /* Checker.getTexColor — rt/texture.d:36-54 */
+        const float *c = &s->tex_color[18 * tex];
+        double size = s->tex_param[6 * tex];
+        int32_t x = d2i_x86(floor(u / size));
+        int32_t y = d2i_x86(floor(v / size));
+        int32_t white = (int32_t)((uint32_t)x + (uint32_t)y) % 2;
+        return white ? colp(c + 3) : colp(c);
+    }
+    case C2RT_TEX_PROCEDURE2: { /* Procedure2.getTexColor — rt/texture.d:77-86 */
+        const float *cu = &s->tex_color[18 * tex], *cv = cu + 9;
+        const double *fu = &s->tex_param[6 * tex], *fv = fu + 3;
+        Col result = col(0, 0, 0);
+        for (int i = 0; i < 3; ++i)
+            result = cadd(result, cadd(cmulf(colp(cu + 3 * i), (float)sin(u * fu[i])),
+                                       cmulf(colp(cv + 3 * i), (float)sin(v * fv[i]))));
+        return result;
+    }
+    default: { /* BitmapTexture.getTexColor — rt/texture.d:116-126 */
+        float scaling = s->tex_scaling[tex];
+        u *= scaling;
+        v *= scaling;
+        u = u - floor(u);
+        v = v - floor(v);
+        float tx = (float)u * (float)s->tex_width[tex];
+        float ty = (float)v * (float)s->tex_height[tex];
+        return bitmap_filtered_pixel(s, tex, tx, ty);
+    }
+    }
+}
+
+/* ===================================================================== */
+/* rt/light.d, rt/shader.d                                                */
+/* ===================================================================== */
+
+/* Light.color — rt/light.d:11-14; PointLight.getNthSample — rt/light.d:61-65 */
+static Col light_color(Scene *s, uint32_t l) { return cmulf(colp(&s->light_color[3 * l]), s->light_power[l]); }
+
+/* Lambert.shade — rt/shader.d:67-105; Phong.shade — rt/shader.d:197-250 */
+static Col shade(Scene *s, int32_t shader, Ray ray, const ID *data, Counters *cnt)
+{
+    int phong = s->shader_type[shader] == C2RT_SHADER_PHONG;
+    V3 N = faceforward_(ray.dir, data->normal);
+    int32_t tex = s->shader_texture[shader];
+    Col diffuseColor = tex >= 0 ? tex_color(s, tex, data->u, data->v) : colp(&s->shader_color[3 * shader]);
+    Col lightContrib = colp(s->ambient);
+    Col specular = col(0, 0, 0);
+    for (uint32_t l = 0; l < s->n_lights; ++l) {
+        const uint32_t numSamples = 1; /* PointLight.getNumSamples — rt/light.d:56-59 */
+        Col avgColor = col(0, 0, 0);
+        Col avgSpecular = col(0, 0, 0);
+        for (uint32_t j = 0; j < numSamples; ++j) {
+            V3 lightPos = v3p(&s->light_pos[3 * l]);
+            Col lightColor = light_color(s, l);
+            if (cintensity(lightColor) != 0 &&
+                test_visibility(s, vadd(data->p, vmul(N, 1e-6)), lightPos, cnt)) {
+                V3 lightDir = vsub(lightPos, data->p);
+                lightDir = vnormalized(lightDir);
+                double cosTheta = vdot(lightDir, N);
+                if (!phong) {
+                    if (cosTheta > 0)
+                        avgColor = cadd(avgColor,
+                                        cmulf(cdivf(lightColor, (float)vsqmag(vsub(data->p, lightPos))),
+                                              (float)cosTheta));
+                } else {
+                    Col baseLight = cdivf(lightColor, (float)vsqmag(vsub(data->p, lightPos)));
+                    if (cosTheta > 0) avgColor = cadd(avgColor, cmulf(baseLight, (float)cosTheta));
+                    V3 R = reflect_(vneg(lightDir), N);
+                    double cosGamma = vdot(R, vneg(ray.dir));
+                    if (cosGamma > 0)
+                        avgSpecular = cadd(avgSpecular,
+                                           cmulf(cmulf(baseLight, (float)pow(cosGamma, s->shader_exponent[shader])),
+                                                 s->shader_strength[shader]));
+                }
+            }
+        }
+        lightContrib = cadd(lightContrib, cdivf(avgColor, (float)numSamples));
+        if (phong) specular = cadd(specular, cdivf(avgSpecular, (float)numSamples));
+    }
+    if (!phong) return cmulc(diffuseColor, lightContrib);
+    return cadd(cmulc(diffuseColor, lightContrib), specular);
+}
+
+/* ===================================================================== */
+/* rt/camera.d                                                            */
+/* ===================================================================== */
+
+void orc_camera_begin_frame(const double pos_[3], double yaw, double pitch, double roll,
+                            double fov, uint32_t frame_width, uint32_t frame_height,
+                            c2rt_camera_frame *out)
+{
+    /* setFrameSize — rt/camera.d:231-236 */
+    double aspect = (double)frame_width / (double)frame_height;
+    /* beginFrame — rt/camera.d:77-117 */
+    double x = -aspect;
+    double y = +1;
+    V3 corner = v3(x, y, 1);
+    V3 center = v3(0, 0, 1);
+    double lenXY = vmag(vsub(corner, center));
+    double wantedLength = tan(radians_(fov / 2));
+    double scaling = wantedLength / lenXY;
+    x *= scaling;
+    y *= scaling;
+    V3 upLeft = v3(x, y, 1), upRight = v3(-x, y, 1), downLeft = v3(x, -y, 1);
+    M3 rotation = m_mul(m_mul(m_rotate_z(radians_(roll)), m_rotate_x(radians_(pitch))),
+                        m_rotate_y(radians_(yaw)));
+    upLeft = mul_vM3(upLeft, rotation);
+    upRight = mul_vM3(upRight, rotation);
+    downLeft = mul_vM3(downLeft, rotation);
+    V3 rightDir = mul_vM3(v3(1, 0, 0), rotation);
+    V3 upDir = mul_vM3(v3(0, 1, 0), rotation);
+    V3 frontDir = mul_vM3(v3(0, 0, 1), rotation);
+    V3 pos = v3p(pos_);
+    upLeft = vadd(upLeft, pos);
+    upRight = vadd(upRight, pos);
+    downLeft = vadd(downLeft, pos);
+    v3store(out->pos, pos);
+    v3store(out->up_left, upLeft);
+    v3store(out->up_right, upRight);
+    v3store(out->down_left, downLeft);
+    v3store(out->right_dir, rightDir);
+    v3store(out->up_dir, upDir);
+    v3store(out->front_dir, frontDir);
+    out->frame_width = (double)frame_width;
+    out->frame_height = (double)frame_height;
+}
+
+/* splitmix64-based counter RNG (build-defined; the reference uses rand()) */
+double orc_rng_uniform(uint64_t seed, uint64_t pixel, uint32_t tap, uint32_t sample, uint32_t dim)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (1 + (((pixel * 8 + tap) * 4096 + sample) * 8 + dim));
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * 0x1p-53;
+}
+
+typedef struct { uint64_t seed, pixel; uint32_t tap, sample, dim; } Rng;
+static double rng_next(Rng *r) { return orc_rng_uniform(r->seed, r->pixel, r->tap, r->sample, r->dim++); }
+
+/* Camera.getScreenRay — rt/camera.d:123-173; offset: 0 none, -1 left, +1 right */
+static Ray screen_ray(const c2rt_camera_frame *cam, double x, double y, int offset, Rng *rng)
+{
+    Ray result;
+    V3 pos = v3p(cam->pos), upLeft = v3p(cam->up_left), upRight = v3p(cam->up_right),
+       downLeft = v3p(cam->down_left), rightDir = v3p(cam->right_dir), upDir = v3p(cam->up_dir),
+       frontDir = v3p(cam->front_dir);
+    result.depth = 0;
+    result.orig = pos;
+    V3 target = vadd(vadd(upLeft, vmul(vsub(upRight, upLeft), x / cam->frame_width)),
+                     vmul(vsub(downLeft, upLeft), y / cam->frame_height));
+    result.dir = vsub(target, pos);
+    result.dir = vnormalized(result.dir);
+    if (offset != 0)
+        result.orig = vadd(result.orig, vmul(rightDir, offset > 0 ? +cam->stereo_separation : -cam->stereo_separation));
+    if (!cam->dof) return result;
+
+    double cosTheta = vdot(result.dir, frontDir);
+    double M = cam->focal_plane_dist / cosTheta;
+    V3 T = vadd(result.orig, vmul(result.dir, M));
+    /* unitDiscSample — rt/camera.d:258-269 */
+    double angle = rng_next(rng) * 2 * ORC_PI;
+    double rad = sqrt(rng_next(rng));
+    double dx = sin(angle) * rad;
+    double dy = cos(angle) * rad;
+    dx *= cam->disc_multiplier;
+    dy *= cam->disc_multiplier;
+    result.orig = vadd(vadd(pos, vmul(rightDir, dx)), vmul(upDir, dy));
+    if (offset != 0)
+        result.orig = vadd(result.orig, vmul(rightDir, offset > 0 ? +cam->stereo_separation : -cam->stereo_separation));
+    result.dir = vsub(T, result.orig);
+    result.dir = vnormalized(result.dir);
+    return result;
+}
+
+/* ===================================================================== */
+/* rt/renderer.d                                                          */
+/* ===================================================================== */
+
+typedef struct {
+    Ray ray;
+    ID data;
+    int32_t closestNode;
+} TraceResult;
+
+/* Renderer.trace + raytrace_impl — rt/renderer.d:325-376 */
+static Col raytrace(Scene *s, Ray ray, Counters *cnt, TraceResult *tr)
+{
+    TraceResult result;
+    result.ray = ray;
+    result.data = id_init();
+    result.closestNode = -1;
+    if (cnt) cnt->primary++;
+    if ((uint32_t)ray.depth > s->max_trace_depth) {
+        if (tr) *tr = result;
+        return col(0, 0, 0);
+    }
+    result.data.dist = 1e99;
+    for (uint32_t n = 0; n < s->n_nodes; ++n)
+        if (node_intersect(s, (int32_t)n, ray, &result.data)) result.closestNode = (int32_t)n;
+    /* lights: PointLight.intersect is always false — rt/light.d:67-70 */
+    if (tr) *tr = result;
+    if (result.closestNode < 0) return col(0, 0, 0); /* Environment — rt/environment.d:7-10 */
+    /* bumpmap.modifyNormal: base-class no-op — rt/texture.d:10-12 */
+    return shade(s, s->node_shader[result.closestNode], result.ray, &result.data, cnt);
+}
+
+typedef struct {
+    Scene *scene;
+    const c2rt_camera_frame *cam;
+    const c2rt_render_opts *opts;
+} RenderCtx;
+
+/* renderSampleDefault / renderSampleDof — rt/renderer.d:270-287,303-313 */
+static Col render_sample(const RenderCtx *rc, double x, double y, uint64_t pixel, uint32_t tap,
+                         Counters *cnt, TraceResult *tr)
+{
+    const c2rt_camera_frame *cam = rc->cam;
+    Rng rng = {rc->opts->seed, pixel, tap, 0, 0};
+    if (cam->dof) {
+        Col average = col(0, 0, 0);
+        for (uint32_t i = 0; i < cam->num_samples; ++i) {
+            rng.sample = i;
+            rng.dim = 0;
+            if (cam->stereo_separation == 0) {
+                double jx = rng_next(&rng), jy = rng_next(&rng);
+                average = cadd(average, raytrace(rc->scene, screen_ray(cam, x + jx * 1, y + jy * 1, 0, &rng), cnt, tr));
+            } else {
+                double jx = rng_next(&rng), jy = rng_next(&rng);
+                Col l = raytrace(rc->scene, screen_ray(cam, x + jx * 1, y + jy * 1, -1, &rng), cnt, tr);
+                jx = rng_next(&rng), jy = rng_next(&rng);
+                Col r = raytrace(rc->scene, screen_ray(cam, x + jx * 1, y + jy * 1, +1, &rng), cnt, NULL);
+                average = cadd(average, combine_stereo(l, r));
+            }
+        }
+        return cdivf(average, (float)cam->num_samples);
+    }
+    if (cam->stereo_separation == 0) return raytrace(rc->scene, screen_ray(cam, x, y, 0, &rng), cnt, tr);
+    Col l = raytrace(rc->scene, screen_ray(cam, x, y, -1, &rng), cnt, tr);
+    Col r = raytrace(rc->scene, screen_ray(cam, x, y, +1, &rng), cnt, NULL);
+    return combine_stereo(l, r);
+}
+
+/* AA kernel — rt/renderer.d:235-242 */
+static const double k_aa_kernel[5][2] = {{0.0, 0.0}, {0.3, 0.3}, {0.6, 0.0}, {0.0, 0.6}, {0.6, 0.6}};
+
+/* interleaved row strips (build-defined) */
+static uint32_t strip_h_(const c2rt_render_opts *o) { return o->strip_height ? o->strip_height : 1; }
+static int row_is_local(const c2rt_render_opts *o, uint32_t y)
+{
+    if (o->strip_world <= 1) return 1;
+    return (y / strip_h_(o)) % o->strip_world == o->strip_rank;
+}
+static uint32_t local_row(const c2rt_render_opts *o, uint32_t y)
+{
+    if (o->strip_world <= 1) return y;
+    uint32_t sh = strip_h_(o);
+    return (y / sh / o->strip_world) * sh + y % sh;
+}
+static uint32_t local_rows(const c2rt_render_opts *o)
+{
+    if (o->strip_world <= 1) return o->height;
+    uint32_t n = 0;
+    for (uint32_t y = 0; y < o->height; ++y) n += (uint32_t)row_is_local(o, y);
+    return n;
+}
+
+typedef struct { int x0, y0, x1, y1; } Box;
+
+typedef struct {
+    RenderCtx rc;
+    float *out;
+    Box *buckets;
+    size_t n_buckets;
+    atomic_size_t next;
+    int pass; /* 2 or 3 */
+    atomic_ullong primary, shadow;
+} Job;
+
+/* renderPixelNoAA — rt/renderer.d:223-228; renderPixelAA — rt/renderer.d:233-251 */
+static void *worker(void *arg)
+{
+    Job *job = (Job *)arg;
+    const c2rt_render_opts *o = job->rc.opts;
+    Counters cnt = {0, 0};
+    uint32_t W = o->width;
+    uint32_t ntaps = o->taps == C2RT_TAPS_REF5 ? 5 : (o->taps == C2RT_TAPS_4 ? 4 : 1);
+    for (;;) {
+        size_t b = atomic_fetch_add(&job->next, 1);
+        if (b >= job->n_buckets) break;
+        Box bx = job->buckets[b];
+        for (int y = bx.y0; y < bx.y1; ++y) {
+            if (!row_is_local(o, (uint32_t)y)) continue;
+            float *row = job->out + 3 * (size_t)local_row(o, (uint32_t)y) * W;
+            for (int x = bx.x0; x < bx.x1; ++x) {
+                uint64_t pixel = (uint64_t)y * W + (uint64_t)x;
+                float *px = row + 3 * (size_t)x;
+                if (job->pass == 2) {
+                    Col c = render_sample(&job->rc, x, y, pixel, 0, &cnt, NULL);
+                    px[0] = c.r, px[1] = c.g, px[2] = c.b;
+                } else {
+                    Col accum = colp(px);
+                    for (uint32_t sample = 1; sample < ntaps; ++sample)
+                        accum = cadd(accum, render_sample(&job->rc, x + k_aa_kernel[sample][0],
+                                                          y + k_aa_kernel[sample][1], pixel, sample, &cnt, NULL));
+                    Col c = cdivf(accum, (float)ntaps); /* `accum / 5`: float division */
+                    px[0] = c.r, px[1] = c.g, px[2] = c.b;
+                }
+            }
+        }
+    }
+    atomic_fetch_add(&job->primary, cnt.primary);
+    atomic_fetch_add(&job->shadow, cnt.shadow);
+    return NULL;
+}
+
+/* getBucketsList — rt/renderer.d:194-213 (bucketSize 48, rt/global_settings.d:16) */
+static Box *bucket_list(int W, int H, size_t *n)
+{
+    const int BUCKET_SIZE = 48;
+    int BW = (W - 1) / BUCKET_SIZE + 1;
+    int BH = (H - 1) / BUCKET_SIZE + 1;
+    Box *res = (Box *)malloc(sizeof(Box) * (size_t)BW * (size_t)BH);
+    size_t k = 0;
+    for (int y = 0; y < BH; y++) {
+        if (y % 2 == 0)
+            for (int x = 0; x < BW; x++) {
+                Box b = {x * BUCKET_SIZE, y * BUCKET_SIZE, (x + 1) * BUCKET_SIZE, (y + 1) * BUCKET_SIZE};
+                res[k++] = b;
+            }
+        else
+            for (int x = BW - 1; x >= 0; x--) {
+                Box b = {x * BUCKET_SIZE, y * BUCKET_SIZE, (x + 1) * BUCKET_SIZE, (y + 1) * BUCKET_SIZE};
+                res[k++] = b;
+            }
+    }
+    for (size_t i = 0; i < k; ++i) { /* clip — rt/imported_types.d:31-35 */
+        if (res[i].x1 > W) res[i].x1 = W;
+        if (res[i].y1 > H) res[i].y1 = H;
+    }
+    *n = k;
+    return res;
+}
+
+static int check_args(Scene *s, const c2rt_camera_frame *cam, const c2rt_render_opts *o)
+{
+    if (!s || !cam || !o) return C2RT_ERR_INVALID_ARG;
+    if (s->gi_enabled) return C2RT_ERR_UNSUPPORTED;
+    if (o->width == 0 || o->height == 0) return C2RT_ERR_INVALID_ARG;
+    if (o->taps != C2RT_TAPS_1 && o->taps != C2RT_TAPS_REF5 && o->taps != C2RT_TAPS_4) return C2RT_ERR_INVALID_ARG;
+    if (o->strip_world > 1 && o->strip_rank >= o->strip_world) return C2RT_ERR_INVALID_ARG;
+    return C2RT_OK;
+}
+
+/* Renderer.renderRT — rt/renderer.d:83-192 (prepass and the dead AA-detection
+ * pass :150-178 have no effect on the final frame and are not restated) */
+int orc_render_frame(const c2rt_scene_desc *scene, const c2rt_camera_frame *cam,
+                     const c2rt_render_opts *opts, float *out_rgb, uint32_t n_threads,
+                     c2rt_ray_stats *stats)
+{
+    int st = check_args(scene, cam, opts);
+    if (st != C2RT_OK) return st;
+    if (!out_rgb) return C2RT_ERR_INVALID_ARG;
+    if (n_threads == 0) {
+        long n = sysconf(_SC_NPROCESSORS_ONLN);
+        n_threads = n > 0 ? (uint32_t)n : 1;
+    }
+    Job job;
+    job.rc.scene = scene;
+    job.rc.cam = cam;
+    job.rc.opts = opts;
+    job.out = out_rgb;
+    job.buckets = bucket_list((int)opts->width, (int)opts->height, &job.n_buckets);
+    atomic_init(&job.primary, 0);
+    atomic_init(&job.shadow, 0);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
+    int passes = opts->taps == C2RT_TAPS_1 ? 1 : 2;
+    for (int p = 0; p < passes; ++p) {
+        job.pass = 2 + p;
+        atomic_init(&job.next, 0);
+        if (n_threads == 1) {
+            worker(&job);
+        } else {
+            for (uint32_t i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, worker, &job);
+            for (uint32_t i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
+        }
+    }
+    free(th);
+    free(job.buckets);
+    if (stats) {
+        stats->primary_rays = atomic_load(&job.primary);
+        stats->shadow_rays = atomic_load(&job.shadow);
+    }
+    return C2RT_OK;
+}
+
+/* renderPixel — rt/renderer.d:46-57 */
+int orc_render_pixel(const c2rt_scene_desc *scene, const c2rt_camera_frame *cam,
+                     const c2rt_render_opts *opts, int x, int y, c2rt_trace_result *out)
+{
+    int st = check_args(scene, cam, opts);
+    if (st != C2RT_OK) return st;
+    if (!out) return C2RT_ERR_INVALID_ARG;
+    RenderCtx rc = {scene, cam, opts};
+    TraceResult tr;
+    memset(&tr, 0, sizeof tr);
+    Col c = render_sample(&rc, x, y, (uint64_t)y * opts->width + (uint64_t)x, 0, NULL, &tr);
+    out->color[0] = c.r, out->color[1] = c.g, out->color[2] = c.b;
+    out->closest_node = tr.closestNode;
+    out->leaf_geom = tr.closestNode >= 0 ? tr.data.g : -1;
+    v3store(out->p, tr.data.p);
+    v3store(out->normal, tr.data.normal);
+    out->dist = tr.data.dist;
+    out->u = tr.data.u;
+    out->v = tr.data.v;
+    v3store(out->ray_orig, tr.ray.orig);
+    v3store(out->ray_dir, tr.ray.dir);
+    return C2RT_OK;
+}
+
+/* ===================================================================== */
+/* rt/transform.d (host, cold)                                             */
+/* ===================================================================== */
+
+static void t_store(double t[30], M3 m)
+{
+    M3 inv = m_inverse(m);
+    M3 tinv = m_transposed(inv);
+    memcpy(T_M(t), m.c, sizeof m.c);
+    memcpy(T_INV(t), inv.c, sizeof inv.c);
+    memcpy(T_TINV(t), tinv.c, sizeof tinv.c);
+}
+static M3 t_load(const double t[30])
+{
+    M3 m;
+    memcpy(m.c, t, sizeof m.c);
+    return m;
+}
+/* reset — rt/transform.d:24-30 */
+void orc_transform_reset(double t[30])
+{
+    t_store(t, m_identity());
+    t[27] = t[28] = t[29] = 0.0;
+}
+/* scale — rt/transform.d:32-39; scaledIdentity — rt/imported_types.d:22-29 */
+void orc_transform_scale(double t[30], double x, double y, double z)
+{
+    M3 scaling;
+    memset(&scaling, 0, sizeof scaling);
+    scaling.c[0][0] = x;
+    scaling.c[1][1] = y;
+    scaling.c[2][2] = z;
+    t_store(t, m_mul(t_load(t), scaling));
+}
+/* rotate — rt/transform.d:41-50 */
+void orc_transform_rotate(double t[30], double yaw, double pitch, double roll)
+{
+    M3 m = m_mul(m_mul(m_mul(t_load(t), m_rotate_x(radians_(pitch))), m_rotate_y(radians_(yaw))),
+                 m_rotate_z(radians_(roll)));
+    t_store(t, m);
+}
+/* translate — rt/transform.d:52-55 (overwrites the offset) */
+void orc_transform_translate(double t[30], const double v[3])
+{
+    t[27] = v[0], t[28] = v[1], t[29] = v[2];
+}
+
+/* ===================================================================== */
+/* imageio/bmp.d, rt/color.d (texture prep, cold)                          */
+/* ===================================================================== */
+
+static uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+/* loadBmpImpl — imageio/bmp.d:60-193; Color(uint) — rt/color.d:60-66 */
+float *orc_bmp_decode(const uint8_t *bytes, size_t len, uint32_t *width, uint32_t *height,
+                      uint32_t **raw_rgb32)
+{
+    if (raw_rgb32) *raw_rgb32 = NULL;
+    if (!bytes || len < 14 + 12) return NULL;
+    if (bytes[0] != 'B' || bytes[1] != 'M') return NULL; /* FileSignature.Win */
+    uint32_t offsetToPixelArray = rd32(bytes + 10);
+    uint32_t ver = rd32(bytes + 14);
+    int32_t w, h;
+    uint32_t planes, bpp, colorsUsed = 0;
+    size_t paletteElem;
+    if (ver == 12) { /* BITMAPCOREHEADER */
+        if (len < 14 + 12) return NULL;
+        w = (int16_t)rd16(bytes + 18);
+        h = (int16_t)rd16(bytes + 20);
+        planes = rd16(bytes + 22);
+        bpp = rd16(bytes + 24);
+        paletteElem = 3;
+    } else if (ver == 40 || ver == 52 || ver == 56 || ver == 108 || ver == 124) {
+        if (len < 14 + 40) return NULL;
+        w = (int32_t)rd32(bytes + 18);
+        h = (int32_t)rd32(bytes + 22);
+        planes = rd16(bytes + 26);
+        bpp = rd16(bytes + 28);
+        colorsUsed = rd32(bytes + 46);
+        paletteElem = 4;
+    } else
+        return NULL;
+    if (planes != 1) return NULL;
+    if (!(bpp == 8 || bpp == 24 || bpp == 32)) return NULL; /* oracle scope: formats the scenes use */
+    if (w <= 0 || h <= 0) return NULL;
+    const uint8_t *palette = bytes + 14 + ver;
+    uint32_t paletteSize = 0;
+    if (bpp == 8) {
+        paletteSize = (ver != 12 && colorsUsed) ? colorsUsed : (1u << bpp);
+        if ((size_t)(palette - bytes) + paletteSize * paletteElem > len) return NULL;
+    }
+    size_t row_size = (size_t)(bpp / 8) * (size_t)w;
+    size_t row_size_padding = (((size_t)bpp * (size_t)w + 31) / 32) * 4;
+    size_t n = (size_t)w * (size_t)h;
+    float *out = (float *)malloc(n * 3 * sizeof(float));
+    uint32_t *raw = (uint32_t *)malloc(n * sizeof(uint32_t));
+    const uint8_t *cur = bytes + offsetToPixelArray;
+    const uint8_t *end = bytes + len;
+    for (int32_t y = h - 1; y >= 0; --y) { /* foreach_reverse: file rows are bottom-up */
+        size_t need = (bpp == 8) ? (size_t)w : row_size;
+        if (cur + need > end) { free(out); free(raw); return NULL; }
+        for (int32_t x = 0; x < w; ++x) {
+            uint32_t rgb;
+            if (bpp == 24)
+                rgb = cur[3 * x] | (cur[3 * x + 1] << 8) | (cur[3 * x + 2] << 16);
+            else if (bpp == 32)
+                rgb = rd32(cur + 4 * x);
+            else {
+                uint32_t idx = cur[x];
+                if (idx >= paletteSize) { free(out); free(raw); return NULL; } /* D: RangeError */
+                const uint8_t *pe = palette + idx * paletteElem;
+                rgb = pe[0] | (pe[1] << 8) | (pe[2] << 16) | (paletteElem == 4 ? ((uint32_t)pe[3] << 24) : 0);
+            }
+            raw[(size_t)y * w + x] = rgb;
+        }
+        /* 24/32 bpp skip the row padding; the <=8 bpp branch reads `width`
+         * bytes and does NOT skip padding (imageio/bmp.d:167-170) */
+        cur += (bpp == 8) ? (size_t)w : row_size_padding;
+    }
+    const float divider = 1.0f / 255.0f;
+    for (size_t i = 0; i < n; ++i) {
+        out[3 * i + 0] = (float)((raw[i] >> 16) & 0xff) * divider;
+        out[3 * i + 1] = (float)((raw[i] >> 8) & 0xff) * divider;
+        out[3 * i + 2] = (float)((raw[i] >> 0) & 0xff) * divider;
+    }
+    *width = (uint32_t)w;
+    *height = (uint32_t)h;
+    if (raw_rgb32) *raw_rgb32 = raw; else free(raw);
+    return out;
+}
+
+/* decompressGamma_sRGB / decompressGamma — rt/bitmap.d:116-136; D's float
+ * `^^` evaluates in extended precision and rounds once to float */
+void orc_texture_gamma(float *texels, size_t n_floats, float assumed_gamma)
+{
+    if (assumed_gamma == 2.2f) {
+        for (size_t i = 0; i < n_floats; ++i) {
+            float x = texels[i];
+            if (x == 0) texels[i] = 0.0f;
+            else if (x == 1) texels[i] = 1.0f;
+            else if (x <= 0.04045f) texels[i] = x / 12.92f;
+            else texels[i] = (float)pow((double)((x + 0.055f) / 1.055f), (double)2.4f);
+        }
+    } else if (assumed_gamma != 1 && assumed_gamma > 0 && assumed_gamma < 10) {
+        for (size_t i = 0; i < n_floats; ++i) {
+            float x = texels[i];
+            if (x == 0) texels[i] = 0.0f;
+            else if (x == 1) texels[i] = 1.0f;
+            else texels[i] = (float)pow((double)x, (double)assumed_gamma);
+        }
+    }
+}
+
+void orc_free(void *p) { free(p); }
+
+/* ===================================================================== */
+/* unit-level entry points                                                 */
+/* ===================================================================== */
+
+static ID id_from(const orc_hit *h)
+{
+    ID d;
+    d.p = v3p(h->p); d.normal = v3p(h->normal);
+    d.dist = h->dist; d.u = h->u; d.v = h->v; d.g = h->g;
+    d.dNdx = v3p(h->dNdx); d.dNdy = v3p(h->dNdy);
+    return d;
+}
+static void id_to(orc_hit *h, const ID *d)
+{
+    v3store(h->p, d->p); v3store(h->normal, d->normal);
+    h->dist = d->dist; h->u = d->u; h->v = d->v; h->g = d->g;
+    v3store(h->dNdx, d->dNdx); v3store(h->dNdy, d->dNdy);
+}
+int orc_geom_intersect(const c2rt_scene_desc *scene, int32_t geom, const double orig[3],
+                       const double dir[3], orc_hit *hit)
+{
+    Ray r = {v3p(orig), v3p(dir), 0};
+    ID d = id_from(hit);
+    int ok = geom_intersect(scene, geom, r, &d);
+    id_to(hit, &d);
+    return ok;
+}
+int orc_geom_is_inside(const c2rt_scene_desc *scene, int32_t geom, const double p[3])
+{
+    return geom_is_inside(scene, geom, v3p(p));
+}
+int orc_node_intersect(const c2rt_scene_desc *scene, int32_t node, const double orig[3],
+                       const double dir[3], orc_hit *hit)
+{
+    Ray r = {v3p(orig), v3p(dir), 0};
+    ID d = id_from(hit);
+    int ok = node_intersect(scene, node, r, &d);
+    id_to(hit, &d);
+    return ok;
+}
+void orc_tex_color(const c2rt_scene_desc *scene, int32_t tex, double u, double v, float out_rgb[3])
+{
+    Col c = tex_color(scene, tex, u, v);
+    out_rgb[0] = c.r, out_rgb[1] = c.g, out_rgb[2] = c.b;
+}
+void orc_screen_ray(const c2rt_camera_frame *cam, double x, double y, double orig[3], double dir[3])
+{
+    c2rt_camera_frame c = *cam;
+    c.dof = 0;
+    c.stereo_separation = 0;
+    Ray r = screen_ray(&c, x, y, 0, NULL);
+    v3store(orig, r.orig);
+    v3store(dir, r.dir);
+}
+int orc_test_visibility(const c2rt_scene_desc *scene, const double from[3], const double to[3])
+{
+    return test_visibility(scene, v3p(from), v3p(to), NULL);
+}
+void orc_shell_sort_hits(orc_hit *arr, size_t n)
+{
+    ID *tmp = (ID *)malloc(sizeof(ID) * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) tmp[i] = id_from(&arr[i]);
+    shell_sort_ids(tmp, n);
+    for (size_t i = 0; i < n; ++i) id_to(&arr[i], &tmp[i]);
+    free(tmp);
+}
