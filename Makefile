@@ -11,13 +11,16 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -fhip-fp32-
               -Wall -Wno-unused-function $(EXTRA_HIPFLAGS)
 CXXFLAGS   := -O2 -std=c++17 -fPIC $(FPFLAGS) -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 CSRC       := chess2rt_amd/csrc
-BUILD      := build
+# development knob: `make VARIANT=name EXTRA_HIPFLAGS=...` builds chess2rt_amd/libc2rt_name.so
+VARIANT    ?=
+BUILD      := build$(if $(VARIANT),_$(VARIANT))
+LIBNAME    := chess2rt_amd/libc2rt$(if $(VARIANT),_$(VARIANT)).so
 
 UNITS      := 0 1 2 3 4 5
 KOBJS      := $(foreach u,$(UNITS),$(BUILD)/c2rt_kernels_u$(u).o)
 HOBJS      := $(BUILD)/c2rt_api.o $(BUILD)/dsc.o $(BUILD)/scene.o $(BUILD)/host_api.o
 
-all: chess2rt_amd/libc2rt.so oracle/libc2rt_oracle.so
+all: $(LIBNAME) oracle/libc2rt_oracle.so
 
 $(BUILD):
 	mkdir -p $(BUILD)
@@ -26,12 +29,12 @@ $(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_device.h inclu
 	$(HIPCC) $(HIPFLAGS) -DC2RT_UNIT=$* -c $< -o $@
 
 $(BUILD)/c2rt_api.o: $(CSRC)/c2rt_api.cpp $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
-	g++ $(CXXFLAGS) -c $< -o $@
+	g++ $(CXXFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
 
 $(BUILD)/%.o: $(CSRC)/host/%.cpp $(CSRC)/host/scene.hpp $(CSRC)/host/dsc.hpp include/c2rt.h include/c2rt_host.h | $(BUILD)
 	g++ $(CXXFLAGS) -c $< -o $@
 
-chess2rt_amd/libc2rt.so: $(KOBJS) $(HOBJS)
+$(LIBNAME): $(KOBJS) $(HOBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
 
 # CPU oracle: plain C restatement of the reference algorithm (tests only)
@@ -39,6 +42,6 @@ oracle/libc2rt_oracle.so: oracle/c2rt_oracle.c oracle/c2rt_oracle.h include/c2rt
 	$(CC) -O2 -std=gnu11 -fPIC -shared $(FPFLAGS) -Wall -o $@ oracle/c2rt_oracle.c -lm -lpthread
 
 clean:
-	rm -rf $(BUILD) chess2rt_amd/libc2rt.so oracle/libc2rt_oracle.so
+	rm -rf build build_* chess2rt_amd/libc2rt*.so oracle/libc2rt_oracle.so
 
 .PHONY: all clean

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libc2rt.so")
+# C2RT_LIB_VARIANT is a development knob (A/B builds from `make VARIANT=x`)
+_VARIANT = os.environ.get("C2RT_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "libc2rt%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 
 # ---- enums (include/c2rt.h) -------------------------------------------------
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_LIMIT, ERR_NO_SCENE, ERR_CANCELLED, ERR_IO, ERR_PARSE = range(10)

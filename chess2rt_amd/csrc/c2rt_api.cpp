@@ -172,6 +172,7 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
     p.local_rows = local_rows_of(o, p.strip_rank);
     p.tiles_x = (o->width + kTileW - 1) / kTileW;
     p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
+    p.blocks_x = (p.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     p.seed = o->seed;
 }
 

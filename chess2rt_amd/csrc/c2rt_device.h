@@ -21,6 +21,11 @@ constexpr int kMaxCsgHits = C2RT_MAX_CSG_HITS; /* per CSG child per ray */
 constexpr int kCsgEntries = 2 * kMaxCsgHits;
 constexpr int kTileW = 8, kTileH = 8;          /* one wavefront = one 8x8 pixel tile */
 constexpr int kWave = 64;
+#ifndef C2RT_WAVES_PER_BLOCK
+#define C2RT_WAVES_PER_BLOCK 1
+#endif
+constexpr int kWavesPerBlock = C2RT_WAVES_PER_BLOCK; /* horizontally adjacent tiles per workgroup */
+constexpr int kBlockThreads = kWave * kWavesPerBlock;
 /* LDS bytes one wavefront needs per CSG nesting level: dist[16][64] + tag[16][64] */
 constexpr int kCsgLdsPerLevel = kCsgEntries * kWave * (8 + 4);
 
@@ -86,6 +91,7 @@ struct RenderParams {
     uint32_t strip_height, strip_rank, strip_world;
     uint32_t local_rows;
     uint32_t tiles_x, tiles_y;     /* tile grid over the LOCAL rows */
+    uint32_t blocks_x;             /* ceil(tiles_x / kWavesPerBlock) */
     uint64_t seed;
     float *out;                    /* local_rows * width * 3 floats */
     unsigned long long *ray_counters; /* [2] primary, shadow (nullable) */

@@ -29,8 +29,14 @@ namespace c2rt {
 namespace {
 
 #define DEV __device__ __forceinline__
+/* Register budget: measured on MI355X (profiles/), 3 waves/SIMD (168 VGPRs) is
+ * the best trade between spills and latency hiding for this fp64 trace; with no
+ * hint hipcc takes all 512 registers and runs one wave per SIMD (1.8x slower). */
 #ifndef C2RT_OCC
-#define C2RT_OCC
+#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
+#ifndef C2RT_XCD_SWIZZLE
+#define C2RT_XCD_SWIZZLE 1
 #endif
 
 /* ------------------------------------------------------------------ */
@@ -675,18 +681,26 @@ __constant__ double k_aa_y[5] = {0.0, 0.3, 0.0, 0.6, 0.6};
  * pixel).  One workgroup = one wavefront = one 8x8 tile.
  */
 template <int LEVELS, bool DOF>
-__global__ void __launch_bounds__(kWave) C2RT_OCC render_kernel(const RenderParams P)
+__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const RenderParams P)
 {
-    extern __shared__ __align__(16) char lds[];
-    const int lane = threadIdx.x;
+    extern __shared__ __align__(16) char lds_all[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    char *lds = lds_all + (size_t)wave * LEVELS * kCsgLdsPerLevel;
 
     /* XCD-aware block -> tile: blocks b and b+8 share an XCD (round-robin
      * dispatch), so XCD x gets tile rows x, x+8, x+16, ... and walks them
-     * left to right. */
+     * left to right.  A block is kWavesPerBlock horizontally adjacent 8x8
+     * tiles, one per wavefront. */
     const uint32_t b = blockIdx.x;
+#if C2RT_XCD_SWIZZLE
     const uint32_t xcd = b & 7u, j = b >> 3;
-    const uint32_t trow = (j / P.tiles_x) * 8u + xcd, tcol = j % P.tiles_x;
+    const uint32_t trow = (j / P.blocks_x) * 8u + xcd, bcol = j % P.blocks_x;
+#else
+    const uint32_t trow = b / P.blocks_x, bcol = b % P.blocks_x;
+#endif
     if (trow >= P.tiles_y) return;
+    const uint32_t tcol = bcol * kWavesPerBlock + wave;
 
     const uint32_t x = tcol * kTileW + (lane & 7);
     const uint32_t lr = trow * kTileH + (lane >> 3); /* local row */
@@ -807,9 +821,13 @@ template <>
 int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
+#if C2RT_XCD_SWIZZLE
     const uint32_t tiles_y_pad = (p.tiles_y + 7u) / 8u * 8u;
-    const dim3 grid(p.tiles_x * tiles_y_pad), block(kWave);
-    const size_t lds = (size_t)C2RT_UNIT * kCsgLdsPerLevel;
+#else
+    const uint32_t tiles_y_pad = p.tiles_y;
+#endif
+    const dim3 grid(p.blocks_x * tiles_y_pad), block(kBlockThreads);
+    const size_t lds = (size_t)C2RT_UNIT * kCsgLdsPerLevel * kWavesPerBlock;
     if (dof_or_stereo)
         hipLaunchKernelGGL((render_kernel<C2RT_UNIT, true>), grid, block, lds, s, p);
     else

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Summarises a scripts/profile.sh output directory into one JSON + the
+kernel-stats CSV (per-launch averages for the render kernel), for committing
+under profiles/."""
+import csv, json, os, sys, statistics
+from collections import defaultdict
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+KERNEL = "render_kernel"
+summ = {"tag": tag, "kernel": None}
+
+with open(os.path.join(src, "trace", "trace_kernel_stats.csv")) as f:
+    rows = list(csv.DictReader(f))
+summ["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows]
+with open(os.path.join(src, "trace", "trace_kernel_trace.csv")) as f:
+    tr = [r for r in csv.DictReader(f) if KERNEL in r["Kernel_Name"]]
+durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
+summ["kernel"] = tr[0]["Kernel_Name"]
+summ["launches"] = len(durs)
+timed = durs[-20:]  # the last 20 launches are bench.py's timed steps
+summ["avg_duration_us_timed"] = statistics.mean(timed) / 1e3
+summ["median_duration_us_timed"] = statistics.median(timed) / 1e3
+for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X"):
+    summ[k] = tr[0][k]
+
+counters = defaultdict(list)
+pmc_dur = {}
+for sub in sorted(os.listdir(src)):
+    p = os.path.join(src, sub, "pmc_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    with open(p) as f:
+        for r in csv.DictReader(f):
+            if KERNEL in r["Kernel_Name"]:
+                counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                pmc_dur.setdefault(sub, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+summ["pmc_per_launch_avg"] = {k: statistics.mean(v[-20:]) for k, v in counters.items()}
+summ["pmc_pass_avg_duration_us"] = {k: statistics.mean(v[-20 * (len(v) // 24 or 1):]) / 1e3 for k, v in pmc_dur.items()}
+c = summ["pmc_per_launch_avg"]
+d = {}
+if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
+    d["valu_active_over_busy"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_BUSY_CYCLES"]
+if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+    d["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
+    d["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    # rocprofv3 reports both in KiB
+    d["fetch_bytes"] = c["FETCH_SIZE"] * 1024
+    d["write_bytes"] = c["WRITE_SIZE"] * 1024
+    d["hbm_bytes_per_launch"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+summ["derived"] = d
+os.makedirs(dst, exist_ok=True)
+with open(os.path.join(dst, "%s_summary.json" % tag), "w") as f:
+    json.dump(summ, f, indent=1)
+with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
+    f.write(open(os.path.join(src, "trace", "trace_kernel_stats.csv")).read())
+print(json.dumps(summ, indent=1))
