@@ -1,0 +1,111 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares;
+ctypes mirrors have the C layout.  No compute calls (runs without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from chess2rt_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    names = re.findall(r"\b(c2rt_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+@pytest.mark.parametrize("header,table", [("c2rt.h", _abi.C2RT_SYMBOLS), ("c2rt_host.h", _abi.C2RT_HOST_SYMBOLS)])
+def test_every_declared_symbol_is_exported(header, table):
+    lib = _abi.load_library()
+    declared = declared_functions(header)
+    assert declared, header
+    for name in declared:
+        assert hasattr(lib, name), "%s declared in include/%s but not exported" % (name, header)
+    # and the ctypes table covers exactly what the header declares
+    assert sorted(table) == declared
+
+
+def test_abi_version_and_status_strings():
+    lib = _abi.load_library()
+    assert lib.c2rt_abi_version() == _abi.ABI_VERSION
+    for st in range(10):
+        assert lib.c2rt_status_string(st)
+    assert b"CPU fallback" in lib.c2rt_status_string(_abi.ERR_NO_DEVICE)
+
+
+def test_struct_layouts_match_c(tmp_path):
+    src = tmp_path / "sizes.c"
+    src.write_text('''
+#include <stdio.h>
+#include <stddef.h>
+#include "c2rt_host.h"
+#include "../oracle/c2rt_oracle.h"
+int main(void) {
+  printf("SceneDesc %zu\\n", sizeof(c2rt_scene_desc));
+  printf("CameraFrame %zu\\n", sizeof(c2rt_camera_frame));
+  printf("RenderOpts %zu\\n", sizeof(c2rt_render_opts));
+  printf("TraceResult %zu\\n", sizeof(c2rt_trace_result));
+  printf("RayStats %zu\\n", sizeof(c2rt_ray_stats));
+  printf("HostSettings %zu\\n", sizeof(c2rt_host_settings));
+  printf("HostCamera %zu\\n", sizeof(c2rt_host_camera));
+  printf("OrcHit %zu\\n", sizeof(orc_hit));
+  printf("off_scene_texels %zu\\n", offsetof(c2rt_scene_desc, texels));
+  printf("off_scene_ambient %zu\\n", offsetof(c2rt_scene_desc, ambient));
+  printf("off_cam_dof %zu\\n", offsetof(c2rt_camera_frame, dof));
+  printf("off_opts_seed %zu\\n", offsetof(c2rt_render_opts, seed));
+  printf("off_trace_p %zu\\n", offsetof(c2rt_trace_result, p));
+  return 0; }
+''')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    from oracle_lib import OrcHit
+
+    expect = {
+        "SceneDesc": C.sizeof(_abi.SceneDesc), "CameraFrame": C.sizeof(_abi.CameraFrame),
+        "RenderOpts": C.sizeof(_abi.RenderOpts), "TraceResult": C.sizeof(_abi.TraceResult),
+        "RayStats": C.sizeof(_abi.RayStats), "HostSettings": C.sizeof(_abi.HostSettings),
+        "HostCamera": C.sizeof(_abi.HostCamera), "OrcHit": C.sizeof(OrcHit),
+        "off_scene_texels": _abi.SceneDesc.texels.offset, "off_scene_ambient": _abi.SceneDesc.ambient.offset,
+        "off_cam_dof": _abi.CameraFrame.dof.offset, "off_opts_seed": _abi.RenderOpts.seed.offset,
+        "off_trace_p": _abi.TraceResult.p.offset,
+    }
+    assert {k: int(v) for k, v in got.items()} == expect
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """The product path must not fall back to anything when libc2rt.so is absent."""
+    code = "import os; os.environ['C2RT_LIB_VARIANT']='does_not_exist'; import chess2rt_amd as c; c._abi.load_library()"
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert p.returncode != 0
+    assert "no" in p.stderr.lower() and "fallback" in p.stderr.lower()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "chess2rt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_lib" not in text and "c2rt_oracle" not in text and "libc2rt_oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_local_rows_is_pure_host_arithmetic():
+    lib = _abi.load_library()
+    from chess2rt_amd.sharding import local_rows
+
+    for (h, sh, world) in [(480, 8, 2), (1080, 8, 8), (217, 8, 3), (100, 16, 4), (7, 8, 2), (2160, 8, 1)]:
+        total = 0
+        for r in range(world):
+            o = _abi.RenderOpts(width=16, height=h, taps=1, strip_height=sh, strip_rank=r, strip_world=world)
+            n = lib.c2rt_local_rows(C.byref(o))
+            assert n == local_rows(h, sh, r, world)
+            total += n
+        assert total == h

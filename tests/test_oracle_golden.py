@@ -1,0 +1,297 @@
+"""The CPU oracle against (1) the reference's own known-answer vectors (BMP),
+(2) the hand-derived lecture4 anchors, (3) analytic properties of the
+reference algorithm incl. its observable bugs, and (4) the
+committed golden frames / unit vectors (regression).  No GPU."""
+import ctypes as C
+import hashlib
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import chess2rt_amd as c2
+import oracle_lib as orc
+from chess2rt_amd import _abi
+from golden_configs import CONFIGS, SCENES, crop_offsets, load_config
+
+
+def jload(golden_dir, name):
+    return json.load(open(os.path.join(golden_dir, name)))
+
+
+# ---- (1) reference-held vectors: imageio/bmp.d unittests ---------------------
+def test_bmp_known_answers_of_the_reference(golden_dir):
+    for case in jload(golden_dir, "bmp_known_answers.json")["cases"]:
+        data = bytes.fromhex(case["bytes_hex"])
+        rgb, raw = orc.bmp_decode(data)
+        assert raw.shape == (case["height"], case["width"])
+        for key, word in case["pixels_xy"].items():
+            x, y = map(int, key.split(","))
+            assert int(raw[y, x]) == word, (case["name"], key)
+            # Color(uint): byte * (1/255) per channel, alpha ignored — rt/color.d:60-66
+            exp = [np.float32((word >> s) & 0xFF) * np.float32(1.0 / 255.0) for s in (16, 8, 0)]
+            assert list(rgb[y, x]) == exp
+
+
+# ---- (2) hand-derived anchors -------------------------------------------------
+def test_lecture4_anchors(golden_dir):
+    a = jload(golden_dir, "lecture4_anchors.json")
+    scene = c2.parseSceneFromFile(os.path.join(SCENES, a["scene"]))
+    scene.setFrameSize(a["width"], a["height"])
+    scene.setAA(False)
+    cam = scene.beginFrame()
+    for k in ("up_left", "up_right", "down_left"):
+        np.testing.assert_allclose(list(getattr(cam, k)), a["camera"][k], atol=a["camera"]["tolerance"], rtol=0)
+    # the oracle's own Camera.beginFrame agrees bit for bit with the host mirror
+    ocam = _abi.CameraFrame()
+    hc = scene.camera
+    orc.lib().orc_camera_begin_frame(orc.vec3(*hc.pos), hc.yaw, hc.pitch, hc.roll, hc.fov, a["width"], a["height"], C.byref(ocam))
+    for k in ("pos", "up_left", "up_right", "down_left", "right_dir", "up_dir", "front_dir"):
+        assert list(getattr(ocam, k)) == list(getattr(cam, k)), k
+    opts = scene.renderOpts()
+    for px in a["pixels"]:
+        r = orc.render_pixel(scene.desc, cam, opts, px["x"], px["y"])
+        np.testing.assert_allclose(list(r.color), px["rgb"], atol=a["rgb_tolerance"], rtol=0)
+        if px.get("miss"):
+            assert r.closest_node == -1
+        if "p" in px:
+            np.testing.assert_allclose(list(r.p), px["p"], atol=a["geom_tolerance"], rtol=0)
+        if "dir" in px:
+            np.testing.assert_allclose(list(r.ray_dir), px["dir"], atol=1e-6, rtol=0)
+        if "t" in px:
+            assert abs(r.dist - px["t"]) < a["geom_tolerance"]
+
+
+# ---- (3) properties of the reference algorithm --------------------------------
+def _mini_scene(geoms, children=None):
+    """A SceneDesc with only geometries (for Geometry.intersect calls)."""
+    n = len(geoms)
+    d = _abi.SceneDesc()
+    d.abi_version = _abi.ABI_VERSION
+    d.n_geoms = n
+    types = (C.c_int32 * n)(*[g[0] for g in geoms])
+    params = (C.c_double * (4 * n))(*[x for g in geoms for x in g[1]])
+    ch = (C.c_int32 * (2 * n))(*([-1] * (2 * n)))
+    for g, (l, r) in (children or {}).items():
+        ch[2 * g], ch[2 * g + 1] = l, r
+    d.geom_type, d.geom_param, d.geom_child = types, params, ch
+    d._keep = (types, params, ch)
+    return d
+
+
+def _isect(desc, g, o, dvec, dist=1e99):
+    h = orc.OrcHit()
+    h.dist = dist
+    h.g = -1
+    ok = orc.lib().orc_geom_intersect(C.byref(desc), g, orc.vec3(*o), orc.vec3(*dvec), C.byref(h))
+    return ok, h
+
+
+NAN = float("nan")
+
+
+def test_plane_horizon_limit_and_default_nan_limit():
+    d = _mini_scene([(_abi.GEOM_PLANE, (2.0, NAN, 0, 0)), (_abi.GEOM_PLANE, (2.0, 10.0, 0, 0))])
+    ok, h = _isect(d, 0, (0, 165, 0), (0, -0.5, math.sqrt(0.75)))
+    assert ok and h.dist == 326.0 and list(h.normal) == [0, 1, 0] and h.u == h.p[0] and h.v == h.p[2]
+    assert not _isect(d, 0, (0, 165, 0), (0, -0.9e-9, 1))[0]          # d.y > -1e-9: horizon
+    assert not _isect(d, 0, (0, 165, 0), (0, -0.5, math.sqrt(0.75)), dist=325.0)[0]
+    assert _isect(d, 0, (0, -5, 0), (0, 1, 0))[0]                     # from below
+    assert not _isect(d, 1, (0, 165, 0), (0, -0.5, math.sqrt(0.75)))[0]   # |p.z| > limit
+    assert _isect(d, 1, (0, 165, 0), (0, -1, 0))[0]
+    assert not orc.lib().orc_geom_is_inside(C.byref(d), 0, orc.vec3(0, 0, 0))
+
+
+def test_sphere_roots_and_uv():
+    d = _mini_scene([(_abi.GEOM_SPHERE, (0, 0, 10, 2))])
+    ok, h = _isect(d, 0, (0, 0, 0), (0, 0, 1))
+    assert ok and h.dist == 8.0 and list(h.normal) == [0, 0, -1]
+    assert h.u == (math.pi + math.atan2(-2.0, 0.0)) / (2 * math.pi) and abs(h.v - 0.5) < 1e-15
+    ok, h = _isect(d, 0, (0, 0, 10), (0, 0, 1))      # from inside: far root
+    assert ok and h.dist == 2.0
+    assert not _isect(d, 0, (0, 0, 13), (0, 0, 1))[0]  # behind
+    assert not _isect(d, 0, (0, 3, 0), (0, 0, 1))[0]   # Dscr < 0
+    assert not _isect(d, 0, (0, 0, 0), (0, 0, 1), dist=7.9)[0]
+    assert orc.lib().orc_geom_is_inside(C.byref(d), 0, orc.vec3(0, 1.9, 10))
+    assert not orc.lib().orc_geom_is_inside(C.byref(d), 0, orc.vec3(0, 2.0, 10))  # strict <
+
+
+def test_cube_faces_and_permuted_uv():
+    d = _mini_scene([(_abi.GEOM_CUBE, (0, 0, 10, 4))])
+    ok, h = _isect(d, 0, (0.5, 0.25, 0), (0, 0, 1))   # -Z face, found by the (0,2,1) projection
+    assert ok and h.dist == 8.0 and list(h.normal) == [0, 0, -1] and list(h.p) == [0.5, 0.25, 8.0]
+    assert (h.u, h.v) == (0.5, 0.25)                   # u,v stay in permuted coordinates: (p.x-c.x, p.y-c.y)
+    ok, h = _isect(d, 0, (-10, 1, 9), (1, 0, 0))      # -X face via (1,0,2): u = p.y-c.y, v = p.z-c.z
+    assert ok and list(h.normal) == [-1, 0, 0] and (h.u, h.v) == (1.0, -1.0)
+    ok, h = _isect(d, 0, (0, 10, 10), (0, -1, 0))     # +Y face
+    assert ok and h.dist == 8.0 and list(h.normal) == [0, 1, 0]
+    ok, h = _isect(d, 0, (0, 0, 10), (0, 0, 1))       # inside: exits through +Z
+    assert ok and h.dist == 2.0 and list(h.normal) == [0, 0, 1]
+    assert not _isect(d, 0, (0, 0, 0), (1, 0, 0))[0]
+    assert orc.lib().orc_geom_is_inside(C.byref(d), 0, orc.vec3(2, 2, 12))   # <= : faces are inside
+
+
+def test_csg_semantics_and_left_nesting_bug():
+    # 0 cube, 1 sphere (pokes out of the faces), 2 diff(0,1), 3 union(0,1), 4 inter(0,1),
+    # 5 small sphere, 6 union(2,5)  <- LEFT-nested: leaf identity test mis-attributes (F9(b))
+    geoms = [(_abi.GEOM_CUBE, (0, 0, 10, 4)), (_abi.GEOM_SPHERE, (0, 0, 10, 2.5)),
+             (_abi.GEOM_CSG_DIFF, (0, 0, 0, 0)), (_abi.GEOM_CSG_UNION, (0, 0, 0, 0)), (_abi.GEOM_CSG_INTER, (0, 0, 0, 0)),
+             (_abi.GEOM_SPHERE, (0, 0, 5, 0.5)), (_abi.GEOM_CSG_UNION, (0, 0, 0, 0))]
+    d = _mini_scene(geoms, {2: (0, 1), 3: (0, 1), 4: (0, 1), 6: (2, 5)})
+    o, z = (0, 0, 0), (0, 0, 1)
+    ok, h = _isect(d, 3, o, z)                         # union: sphere first at 7.5
+    assert ok and h.dist == 7.5 and h.g == 1
+    ok, h = _isect(d, 4, o, z)                         # inter: cube face at 8
+    assert ok and h.dist == 8.0 and h.g == 0
+    assert not _isect(d, 2, o, z)[0]                   # diff along the axis: the sphere eats the whole chord
+    # off-axis through a corner region: cube entered at 8 outside the sphere
+    o2 = (1.9, 1.9, 0)
+    ok, h = _isect(d, 2, o2, z)
+    assert ok and h.dist == 8.0 and h.g == 0 and list(h.normal) == [0, 0, -1]
+    # isInside = boolOp(left, right)
+    L = orc.lib()
+    assert L.orc_geom_is_inside(C.byref(d), 2, orc.vec3(1.9, 1.9, 10)) and not L.orc_geom_is_inside(C.byref(d), 2, orc.vec3(0, 0, 10))
+    # left-nested union: the hit of child 2 carries leaf g=0 != left(=2), so it toggles inR
+    ok, h = _isect(d, 6, o2, z)
+    assert ok and h.g == 0 and h.dist == 8.0
+    # ... and a ray through the small sphere only: both of its hits toggle inR
+    ok, h = _isect(d, 6, (0, 0, 0), (0, 0, 1), dist=1e99)
+    assert ok and h.g == 5 and h.dist == 4.5
+
+
+def test_csgdiff_flips_the_carved_normal():
+    geoms = [(_abi.GEOM_SPHERE, (0, 0, 10, 3)), (_abi.GEOM_SPHERE, (0, 0, 7.5, 1.5)), (_abi.GEOM_CSG_DIFF, (0, 0, 0, 0))]
+    d = _mini_scene(geoms, {2: (0, 1)})
+    ok, h = _isect(d, 2, (0, 0, 0), (0, 0, 1))
+    # big sphere spans 7..13, small 6..9: first in-diff point is the small sphere's EXIT at 9,
+    # whose outward normal (0,0,1) is flipped to face the carved cavity
+    assert ok and h.dist == pytest.approx(9.0, abs=1e-5) and h.g == 1
+    assert list(h.normal) == [-0.0, -0.0, -1.0] or list(h.normal) == [0, 0, -1]
+
+
+def test_shell_sort_matches_committed_orders(golden_dir):
+    for case in jload(golden_dir, "unit_vectors.json")["shell_sort"]:
+        n = len(case["dist"])
+        arr = (orc.OrcHit * max(n, 1))()
+        for i, v in enumerate(case["dist"]):
+            arr[i].dist, arr[i].g = v, i
+        orc.lib().orc_shell_sort_hits(arr, n)
+        got = [arr[i].g for i in range(n)]
+        assert got == case["order"]
+        assert [case["dist"][g] for g in got] == sorted(case["dist"])
+
+
+def test_checker_negative_modulo_and_x86_cast(scenes_dir):
+    s = c2.parseSceneFromFile(os.path.join(scenes_dir, "lecture4.sdl"))
+
+    def col(u, v):
+        c = (C.c_float * 3)()
+        orc.lib().orc_tex_color(s.desc, 0, u, v, c)
+        return list(c)
+    c1, c2_ = [0, 0, 0], [0, 0.5, 1.0]
+    assert col(0.0, 0.0) == c1 and col(5.0, 0.0) == c2_
+    assert col(-0.001, 0.0) == c2_          # floor(-0.0002) = -1 -> (-1) % 2 = -1 -> "white"
+    assert col(-5.0, -5.0) == c1            # -1 + -1 = -2
+    assert col(1e12, 3.0) == c1             # cast(int) out of range = INT_MIN; INT_MIN + 0 is even
+    assert col(-1e12, -1e12) == c1          # INT_MIN + INT_MIN wraps to 0
+
+
+def test_bitmap_texture_red_at_the_float_rounding_edge(scenes_dir):
+    s = c2.parseSceneFromFile(os.path.join(scenes_dir, "lecture5.sdl"))
+
+    def col(u, v):
+        c = (C.c_float * 3)()
+        orc.lib().orc_tex_color(s.desc, 1, u, v, c)
+        return list(c)
+    assert col(0.99999999, 0.5) == [1.0, 0.0, 0.0]      # float(u) rounds up to 1.0 -> tx == width -> red (F9(e))
+    assert col(0.5, 0.99999999) == [1.0, 0.0, 0.0]
+    assert col(0.999999, 0.5) != [1.0, 0.0, 0.0]
+    assert col(1.0, 1.0) == col(0.0, 0.0)                 # u - floor(u) wraps
+    assert col(float("nan"), 0.5) == [1.0, 0.0, 0.0]
+
+
+def test_aa_is_five_fixed_taps_divided_by_five(scenes_dir):
+    s = c2.parseSceneFromFile(os.path.join(scenes_dir, "lecture4.sdl"))
+    s.setFrameSize(64, 48)
+    cam = s.beginFrame()
+    full = orc.render_frame(s.desc, cam, s.renderOpts(taps=5))
+    # rebuild pixel (40, 30) from single samples of a 10x finer frame: tap offsets 0.3/0.6 land on its grid
+    s.setFrameSize(640, 480)
+    cam10 = s.beginFrame()
+    acc = None
+    for (kx, ky) in [(0, 0), (3, 3), (6, 0), (0, 6), (6, 6)]:
+        r = orc.render_pixel(s.desc, cam10, s.renderOpts(taps=1), 400 + kx, 300 + ky)
+        c = np.array(list(r.color), dtype=np.float32)
+        acc = c if acc is None else (acc + c).astype(np.float32)
+    np.testing.assert_allclose(full[30, 40], acc / np.float32(5), rtol=0, atol=1e-6)
+
+
+def test_gi_is_rejected_and_args_validated(scenes_dir):
+    s = c2.parseSceneFromFile(os.path.join(scenes_dir, "lecture4.sdl"))
+    cam = s.beginFrame()
+    out = np.zeros((4, 4, 3), np.float32)
+    o = s.renderOpts(width=4, height=4, taps=3)
+    assert orc.lib().orc_render_frame(s.desc, C.byref(cam), C.byref(o), out.ctypes.data_as(C.c_void_p), 1, None) == _abi.ERR_INVALID_ARG
+    o = s.renderOpts(width=0, height=4)
+    assert orc.lib().orc_render_frame(s.desc, C.byref(cam), C.byref(o), out.ctypes.data_as(C.c_void_p), 1, None) == _abi.ERR_INVALID_ARG
+
+
+# ---- (4) regression against the committed oracle output -----------------------
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_oracle_reproduces_golden_frames(name, golden_dir):
+    frames = jload(golden_dir, "frames.json")
+    crops = np.load(os.path.join(golden_dir, "frames_crops.npz"))
+    scene, cam, opts = load_config(name)
+    stats = {}
+    img = orc.render_frame(scene.desc, cam, opts, 0, stats)
+    e = frames[name]
+    assert (stats["primary"], stats["shadow"]) == (e["primary_rays"], e["shadow_rays"])
+    for k, (x0, y0) in enumerate(crop_offsets(opts.width, opts.height)):
+        np.testing.assert_allclose(img[y0:y0 + 64, x0:x0 + 64], crops["%s/%d" % (name, k)], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(img.astype(np.float64).mean(axis=(0, 1)), e["mean"], rtol=0, atol=1e-7)
+    if "lecture4_" in name or "zaphod_645" in name:   # no libm on these paths: bit-stable everywhere
+        assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == e["sha256"]
+
+
+def test_oracle_is_deterministic_and_thread_count_independent():
+    scene, cam, opts = load_config("lecture5_333x217_t4")
+    a = orc.render_frame(scene.desc, cam, opts, 1)
+    b = orc.render_frame(scene.desc, cam, opts, 5)
+    assert np.array_equal(a, b)
+
+
+def test_oracle_strips_are_slices_of_the_frame():
+    scene, cam, opts = load_config("csg_stress_320x240_t1")
+    full = orc.render_frame(scene.desc, cam, opts, 0)
+    world = 3
+    for r in range(world):
+        _, _, o = load_config("csg_stress_320x240_t1", strip_height=8, strip_rank=r, strip_world=world)
+        part = orc.render_frame(scene.desc, cam, o, 0)
+        rows = [y for y in range(opts.height) if (y // 8) % world == r]
+        assert np.array_equal(part, full[rows])
+
+
+def test_unit_vectors_regression(golden_dir):
+    from unit_inputs import unit_cases
+
+    want = jload(golden_dir, "unit_vectors.json")
+    got = json.loads(json.dumps(unit_cases(orc, c2)))
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert len(got[k]) == len(want[k]), k
+        for a, b in zip(got[k], want[k]):
+            assert _close(a, b), (k, a, b)
+
+
+def _close(a, b):
+    if isinstance(a, dict):
+        return a.keys() == b.keys() and all(_close(a[k], b[k]) for k in a)
+    if isinstance(a, list):
+        return len(a) == len(b) and all(_close(x, y) for x, y in zip(a, b))
+    if isinstance(a, float) or isinstance(b, float):
+        if a is None or b is None:
+            return a is b
+        return a == b or abs(a - b) <= 1e-12 * max(1.0, abs(a), abs(b))
+    return a == b
