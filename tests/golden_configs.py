@@ -35,5 +35,7 @@ def load_config(name, **opt_overrides):
     scene.setFrameSize(cfg["w"], cfg["h"])
     scene.setDof(bool(cfg["dof"]))
     cam = scene.beginFrame()
-    opts = scene.renderOpts(taps=cfg["taps"], seed=cfg.get("seed", 0), **opt_overrides)
+    kw = dict(taps=cfg["taps"], seed=cfg.get("seed", 0))
+    kw.update(opt_overrides)
+    opts = scene.renderOpts(**kw)
     return scene, cam, opts
