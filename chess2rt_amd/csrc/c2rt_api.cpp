@@ -98,6 +98,70 @@ int csg_depth(const c2rt_scene_desc *s, int32_t g, std::vector<int> &state, std:
     return d;
 }
 
+/* ---- conservative bounds and exact CSG shortcuts (see c2rt_device.h) ---- */
+struct BoundInfo { bool done = false, bounded = false; double c[3] = {0, 0, 0}, r = 0; };
+
+bool subtree_has_leaf(const c2rt_scene_desc *s, int32_t g, int32_t leaf)
+{
+    if (!is_csg(s->geom_type[g])) return g == leaf;
+    return subtree_has_leaf(s, s->geom_child[2 * g], leaf) || subtree_has_leaf(s, s->geom_child[2 * g + 1], leaf);
+}
+
+BoundInfo enclose(const BoundInfo &a, const BoundInfo &b)
+{
+    BoundInfo o;
+    o.done = true;
+    if (!a.bounded || !b.bounded) return o;
+    const double d = std::sqrt((a.c[0] - b.c[0]) * (a.c[0] - b.c[0]) + (a.c[1] - b.c[1]) * (a.c[1] - b.c[1]) + (a.c[2] - b.c[2]) * (a.c[2] - b.c[2]));
+    o.bounded = true;
+    for (int i = 0; i < 3; ++i) o.c[i] = a.c[i]; /* keep a's centre: simple and conservative */
+    o.r = std::fmax(a.r, d + b.r);
+    return o;
+}
+
+/* geometries must already be validated acyclic (csg_depth) */
+BoundInfo bound_of(const c2rt_scene_desc *s, int32_t g, std::vector<BoundInfo> &memo, std::vector<DevGeom> &geoms)
+{
+    if (memo[g].done) return memo[g];
+    BoundInfo b;
+    b.done = true;
+    const int t = s->geom_type[g];
+    const double *p = s->geom_param + 4 * (size_t)g;
+    if (t == C2RT_GEOM_SPHERE) {
+        b.bounded = std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]) && std::isfinite(p[3]);
+        for (int i = 0; i < 3; ++i) b.c[i] = p[i];
+        b.r = std::fabs(p[3]);
+    } else if (t == C2RT_GEOM_CUBE) {
+        b.bounded = std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]) && std::isfinite(p[3]);
+        for (int i = 0; i < 3; ++i) b.c[i] = p[i];
+        b.r = std::fabs(p[3]) * 0.5 * 1.7320508075688774; /* half diagonal */
+    } else if (is_csg(t)) {
+        const int32_t l = s->geom_child[2 * g], r = s->geom_child[2 * g + 1];
+        const BoundInfo bl = bound_of(s, l, memo, geoms), br = bound_of(s, r, memo, geoms);
+        const bool shortA = t != C2RT_GEOM_CSG_UNION && !subtree_has_leaf(s, r, l);
+        const bool shortB = t == C2RT_GEOM_CSG_INTER && !is_csg(s->geom_type[l]);
+        if (shortA) geoms[g].flags |= kCsgShortA;
+        if (shortB) geoms[g].flags |= kCsgShortB;
+        if (shortA && bl.bounded) b = bl;       /* nothing on the left => false */
+        else b = enclose(bl, br);               /* nothing on either side => false */
+        b.done = true;
+    } /* plane: unbounded */
+    if (b.bounded) {
+        /* pad: the reject test runs in fp64 on coordinates of this magnitude */
+        const double mag = std::fabs(b.c[0]) + std::fabs(b.c[1]) + std::fabs(b.c[2]) + b.r;
+        const double rp = b.r * (1 + 1e-6) + 1e-6 * mag + 1e-9;
+        if (std::isfinite(rp) && rp * rp < 1e300) {
+            geoms[g].flags |= kGeomBounded;
+            geoms[g].bound[0] = b.c[0];
+            geoms[g].bound[1] = b.c[1];
+            geoms[g].bound[2] = b.c[2];
+            geoms[g].bound[3] = rp * rp;
+        }
+    }
+    memo[g] = b;
+    return b;
+}
+
 /* convertTo8bit_sRGB — rt/color.d:194-207 (note the 12.02) and the 4097-entry
  * cache built by the module constructor rt/color.d:224-228 */
 void build_srgb_lut(uint8_t *lut)
@@ -297,6 +361,7 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         for (int i = 0; i < 4; ++i) d.p[i] = s->geom_param[4 * g + i];
     }
     std::vector<int> state(s->n_geoms, 0), memo(s->n_geoms, 0);
+    std::vector<BoundInfo> bounds(s->n_geoms);
     int levels = 0;
 
     /* textures: texel pool repacked to float4 */
@@ -369,6 +434,7 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         if (depth < 0) return fail(ctx, C2RT_ERR_INVALID_ARG, "node %u: geometry index out of range or cyclic CSG", n);
         if (depth > C2RT_MAX_CSG_DEPTH) return fail(ctx, C2RT_ERR_LIMIT, "node %u: CSG nesting %d > %d", n, depth, C2RT_MAX_CSG_DEPTH);
         if (depth > levels) levels = depth;
+        bound_of(s, d.geom, bounds, geoms);
         const double *t = s->node_transform + 30 * (size_t)n;
         std::memcpy(d.m, t, 9 * sizeof(double));
         std::memcpy(d.inv, t + 9, 9 * sizeof(double));

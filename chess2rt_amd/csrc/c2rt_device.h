@@ -29,9 +29,28 @@ constexpr int kBlockThreads = kWave * kWavesPerBlock;
 /* LDS bytes one wavefront needs per CSG nesting level: dist[16][64] + tag[16][64] */
 constexpr int kCsgLdsPerLevel = kCsgEntries * kWave * (8 + 4);
 
-struct alignas(16) DevGeom {       /* 48 B */
-    int32_t type, left, right, pad;
+enum GeomFlags : int32_t {
+    kGeomBounded = 1,              /* `bound` is valid: a ray that misses it cannot hit */
+    /* CsgOp shortcuts that are exact under the reference's leaf-identity walk
+     * (`current.g is left`, rt/geometry.d:314-317):
+     * A: no hit on the left child  => intersect() is false (Inter/Diff, and no
+     *    leaf equal to `left` inside the right subtree, which would toggle inL);
+     * B: no hit on the right child => false (Inter with a PRIMITIVE left child;
+     *    a nested left child's hits carry a leaf != left and toggle inR). */
+    kCsgShortA = 2,
+    kCsgShortB = 4,
+};
+
+struct alignas(16) DevGeom {       /* 80 B */
+    int32_t type, left, right;
+    int32_t flags;                 /* GeomFlags */
     double p[4];                   /* plane: y, limit | sphere: c, R | cube: c, side */
+    /* Conservative bounding sphere in object space: centre, radius^2, padded
+     * by 1e-6 relative so that rounding in the reject test can only keep rays,
+     * never drop one the reference would hit.  Built at upload
+     * (c2rt_api.cpp: cube = half diagonal, Union = both children, Inter/Diff =
+     * left child, Plane = unbounded). */
+    double bound[4];
 };
 
 enum NodeFlags : uint32_t {

@@ -86,8 +86,26 @@ DEV int d2i_x86(double d)
 struct Hit {          /* IntersectionData — rt/intersectable.d:6-33 (dNdx/dNdy are dead on this path) */
     D3 p, n;
     double dist, u, v;
+    /* Sphere u,v cost an atan2 and an asin and are only read by textured
+     * shaders: a sphere hit leaves (p.x-c.x, p.z-c.z, (p.y-c.y)/R) in (u, v, w)
+     * with `uv_pending` set, and finish_uv() runs once for the closest hit. */
+    double w;
     int g;
+    bool uv_pending;
+    bool axis_n;      /* n is an exact signed unit axis (plane, cube): normalize(n) == n */
 };
+
+/* Sphere.intersect's u,v — rt/geometry.d:116-118 */
+DEV void finish_uv(Hit &h)
+{
+    if (h.uv_pending) {
+        constexpr double PI = 3.14159265358979323846;
+        const double angle = atan2(h.v, h.u);
+        h.u = (PI + angle) / (2 * PI);
+        h.v = 1.0 - (PI / 2 + asin(h.w)) / PI;
+        h.uv_pending = false;
+    }
+}
 
 /* what a caller needs back from an intersect call */
 enum Need { kBool = 0, kPoint = 1, kFull = 2 };
@@ -103,14 +121,24 @@ struct Ctx {
     int lane;
 };
 
+/* A ray in some object space: origin, unit direction and A = |d|^2 exactly as
+ * Sphere.intersect computes it (rt/geometry.d:96) — the direction is shared by
+ * every geometry under a node and by all steps of findAllIntersections, so A
+ * is evaluated once per direction instead of once per sphere test. */
+struct ORay {
+    D3 o, d;
+    double A;
+};
+
 /* ------------------------------------------------------------------ */
 /* primitives                                                           */
 /* ------------------------------------------------------------------ */
 
 /* Plane.intersect — rt/geometry.d:30-59 */
 template <int NEED>
-DEV bool plane_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
+DEV bool plane_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
 {
+    const D3 o = r.o, d = r.d;
     const double y = G->p[0], limit = G->p[1];
     if ((o.y > y && d.y > -1e-9) || (o.y < y && d.y < 1e-9)) return false;
     const double mult = (o.y - y) / -d.y;
@@ -119,27 +147,34 @@ DEV bool plane_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
     if (fabs(p.x) > limit || fabs(p.z) > limit) return false;
     h.dist = mult;
     if (NEED >= kPoint) { h.p = p; h.g = gid; }
-    if (NEED == kFull) { h.n = mk(0, 1, 0); h.u = p.x; h.v = p.z; }
+    if (NEED == kFull) { h.n = mk(0, 1, 0); h.u = p.x; h.v = p.z; h.uv_pending = false; h.axis_n = true; }
     return true;
 }
 
 /* Sphere.intersect — rt/geometry.d:92-125 */
 template <int NEED>
-DEV bool sphere_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
+DEV bool sphere_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
 {
+    const D3 o = r.o, d = r.d;
     const D3 c = ld3(G->p);
     const double R = G->p[3];
     const D3 H = o - c;
-    const double A = sqmag(d);
+    const double A = r.A;
     const double B = 2 * dot(H, d);
     const double C = sqmag(H) - R * R;
-    const double Dscr = B * B - 4 * A * C;
+    const double BB = B * B;
+    const double Dscr = BB - 4 * A * C;
     if (Dscr < 0) return false;
+    /* Outside the sphere and moving away: sqrt(Dscr) < B by a margin far above
+     * rounding, so both roots are negative — the reference returns false after
+     * a sqrt and two divisions; skip them.  (Near-degenerate cases fall through
+     * to the literal evaluation.) */
+    if (C > 0 && B > 0 && Dscr < BB * (1 - 1e-8)) return false;
     const double sq = sqrt(Dscr);
-    const double x1 = (-B + sq) / (2 * A);
-    const double x2 = (-B - sq) / (2 * A);
-    double sol = x2;
-    if (sol < 0) sol = x1;
+    const double A2 = 2 * A;
+    /* x1 = (-B + sq) / (2A) is only read when x2 < 0 */
+    double sol = (-B - sq) / A2;
+    if (sol < 0) sol = (-B + sq) / A2;
     if (sol < 0) return false;
     if (sol > h.dist) return false;
     h.dist = sol;
@@ -149,10 +184,11 @@ DEV bool sphere_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
         h.g = gid;
         if (NEED == kFull) {
             h.n = normalized(p - c);
-            const double angle = atan2(p.z - c.z, p.x - c.x);
-            constexpr double PI = 3.14159265358979323846;
-            h.u = (PI + angle) / (2 * PI);
-            h.v = 1.0 - (PI / 2 + asin((p.y - c.y) / R)) / PI;
+            h.u = p.x - c.x;
+            h.v = p.z - c.z;
+            h.w = (p.y - c.y) / R;
+            h.uv_pending = true;
+            h.axis_n = false;
         }
     }
     return true;
@@ -161,7 +197,10 @@ DEV bool sphere_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
 /* Cube.intersectCubeSide — rt/geometry.d:198-235, for the face pair whose
  * axis is `ay` after the project() permutation; (ax, az) are the other two
  * axes in permuted order.  Arithmetic is component-wise, so it is evaluated
- * in place instead of permuting (project/unproject, rt/imported_types.d:44-60). */
+ * in place instead of permuting (project/unproject, rt/imported_types.d:44-60).
+ * `mult < 0` is decided from the operand signs (an IEEE quotient is negative
+ * iff exactly one operand is and the numerator is non-zero), which skips the
+ * division for every face behind the origin. */
 template <int NEED>
 DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, double cx,
                     double oz, double dz, double cz, double halfSide, D3 o, D3 d,
@@ -169,10 +208,14 @@ DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, doubl
 {
     if (fabs(dy) < 1e-9) return false;
     bool found = false;
+    const double den = -dy;
 #pragma unroll
     for (int side = -1; side <= 1; side += 2) {
-        const double mult = (oy - (cy + side * halfSide)) / -dy;
-        if (mult < 0) continue;
+        const double num = oy - (cy + side * halfSide);
+        const bool negative = (num < 0) ? (den > 0) : (num > 0 && den < 0);
+        if (negative) continue;          /* mult < 0 */
+        const double mult = num / den;
+        if (mult < 0) continue;          /* kept for NaN / zero corner cases */
         if (mult > h.dist) continue;
         const double px = ox + dx * mult, pz = oz + dz * mult;
         if (px < cx - halfSide || px > cx + halfSide || pz < cz - halfSide || pz > cz + halfSide) continue;
@@ -191,8 +234,9 @@ DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, doubl
 
 /* Cube.intersect — rt/geometry.d:172-196 */
 template <int NEED>
-DEV bool cube_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
+DEV bool cube_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
 {
+    const D3 o = r.o, d = r.d;
     const D3 c = ld3(G->p);
     const double halfSide = G->p[3] * 0.5;
     int axis = 1;
@@ -203,9 +247,26 @@ DEV bool cube_intersect(const DevGeom *G, int gid, D3 o, D3 d, Hit &h)
     found |= cube_sides<NEED>(o.z, d.z, c.z, o.x, d.x, c.x, o.y, d.y, c.y, halfSide, o, d, h, 2, axis, side);
     if (found) {
         if (NEED >= kPoint) h.g = gid;
-        if (NEED == kFull) h.n = mk(axis == 0 ? side : 0.0, axis == 1 ? side : 0.0, axis == 2 ? side : 0.0);
+        if (NEED == kFull) {
+            h.n = mk(axis == 0 ? side : 0.0, axis == 1 ? side : 0.0, axis == 2 ? side : 0.0);
+            h.uv_pending = false;
+            h.axis_n = true;
+        }
     }
     return found;
+}
+
+/* Conservative reject: true when the ray cannot reach the geometry's padded
+ * bounding sphere (DevGeom::bound), in which case Geometry.intersect would
+ * return false after doing all of its work.  |d| = 1 up to rounding and the
+ * radius is padded by 1e-6 relative, so the test only ever errs towards
+ * "may hit". */
+DEV bool misses_bound(const DevGeom *G, const ORay &r)
+{
+    const D3 H = r.o - ld3(G->bound);
+    const double b = dot(H, r.d);
+    const double c = sqmag(H) - G->bound[3];
+    return c > 0 && (b > 0 || b * b < c);
 }
 
 /* isInside — rt/geometry.d:25-28,127-130,165-170,334-337 */
@@ -237,7 +298,7 @@ DEV bool geom_is_inside(const Ctx &cx, int gid, D3 p)
 /* ------------------------------------------------------------------ */
 
 template <int LEVEL, int NEED>
-__device__ bool geom_intersect(const Ctx &cx, int gid, D3 o, D3 d, Hit &h);
+__device__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h);
 
 /* CsgOp.intersect (+ CsgDiff.intersect) for a CSG whose subtree has at most
  * LEVEL nesting levels.  The hit lists of findAllIntersections
@@ -248,38 +309,38 @@ __device__ bool geom_intersect(const Ctx &cx, int gid, D3 o, D3 d, Hit &h);
  * `current.g is left` leaf-identity test), and the winning hit is then
  * re-derived by replaying its child's stepping up to k. */
 template <int LEVEL, int NEED>
-__device__ bool csg_intersect(const Ctx &cx, const DevGeom *G, D3 o, D3 d, Hit &h)
+__device__ bool csg_intersect(const Ctx &cx, const DevGeom *G, const ORay &ray, Hit &h)
 {
     static_assert(LEVEL >= 1, "CSG needs a slab");
     double *ldist = reinterpret_cast<double *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel) + cx.lane;
     uint32_t *ltag = reinterpret_cast<uint32_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
-    const int type = G->type, left = G->left, right = G->right;
+    const int type = G->type, left = G->left, right = G->right, flags = G->flags;
+    const D3 d = ray.d;
 
     int nL = 0, nR = 0;
     int n = 0;
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
         const int child = side ? right : left;
-        D3 oo = o;
+        ORay rr = ray;
         double cur = 0;
         int k = 0;
         while (k < kMaxCsgHits) {
             Hit t;
             t.dist = 1e99;
-            if (!geom_intersect<LEVEL - 1, kPoint>(cx, child, oo, d, t)) break;
+            if (!geom_intersect<LEVEL - 1, kPoint>(cx, child, rr, t)) break;
             t.dist += cur;
             cur = t.dist;
-            oo = t.p + d * 1e-6;
+            rr.o = t.p + d * 1e-6;
             ldist[(n + k) * kWave] = t.dist;
             ltag[(n + k) * kWave] = ((uint32_t)t.g << 8) | ((uint32_t)side << 4) | (uint32_t)k;
             ++k;
         }
         if (side == 0) nL = k; else nR = k;
         n += k;
-        /* exact shortcuts: with no left hit inL stays false, so Inter and Diff
-         * can never fire; with no right hit Inter cannot either. */
-        if (side == 0 && k == 0 && type != C2RT_GEOM_CSG_UNION) return false;
-        if (side == 1 && k == 0 && type == C2RT_GEOM_CSG_INTER) return false;
+        /* exact shortcuts (GeomFlags): nothing can switch the operator on */
+        if (side == 0 && k == 0 && (flags & kCsgShortA)) return false;
+        if (side == 1 && k == 0 && (flags & kCsgShortB)) return false;
     }
 
     /* sort — util/array.d:95-111 (index rewound by the inner while) */
@@ -316,19 +377,19 @@ __device__ bool csg_intersect(const Ctx &cx, const DevGeom *G, D3 o, D3 d, Hit &
     const uint32_t wtag = ltag[win * kWave];
     const int wside = (wtag >> 4) & 1, wk = wtag & 15;
     const int child = wside ? right : left;
-    D3 oo = o;
+    ORay rr = ray;
     double cur = 0;
     for (int i = 0; i < wk; ++i) {
         Hit t;
         t.dist = 1e99;
-        geom_intersect<LEVEL - 1, kPoint>(cx, child, oo, d, t);
+        geom_intersect<LEVEL - 1, kPoint>(cx, child, rr, t);
         t.dist += cur;
         cur = t.dist;
-        oo = t.p + d * 1e-6;
+        rr.o = t.p + d * 1e-6;
     }
     Hit t;
     t.dist = 1e99;
-    geom_intersect<LEVEL - 1, NEED>(cx, child, oo, d, t);
+    geom_intersect<LEVEL - 1, NEED>(cx, child, rr, t);
     t.dist += cur;
     h = t;
 
@@ -341,24 +402,24 @@ __device__ bool csg_intersect(const Ctx &cx, const DevGeom *G, D3 o, D3 d, Hit &
 
 /* levels >= 2 are real calls so that code size stays linear in the depth */
 template <int LEVEL, int NEED>
-__device__ __noinline__ bool csg_intersect_call(const Ctx &cx, const DevGeom *G, D3 o, D3 d, Hit &h)
+__device__ __noinline__ bool csg_intersect_call(const Ctx &cx, const DevGeom *G, const ORay &r, Hit &h)
 {
-    return csg_intersect<LEVEL, NEED>(cx, G, o, d, h);
+    return csg_intersect<LEVEL, NEED>(cx, G, r, h);
 }
 
 /* Geometry.intersect: `gid` is wave-uniform, so this is a scalar branch. */
 template <int LEVEL, int NEED>
-__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, D3 o, D3 d, Hit &h)
+__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h)
 {
     const DevGeom *G = cx.geoms + gid;
     const int type = G->type;
-    if (type == C2RT_GEOM_PLANE) return plane_intersect<NEED>(G, gid, o, d, h);
-    if (type == C2RT_GEOM_SPHERE) return sphere_intersect<NEED>(G, gid, o, d, h);
-    if (type == C2RT_GEOM_CUBE) return cube_intersect<NEED>(G, gid, o, d, h);
+    if (type == C2RT_GEOM_PLANE) return plane_intersect<NEED>(G, gid, r, h);
+    if (type == C2RT_GEOM_SPHERE) return sphere_intersect<NEED>(G, gid, r, h);
+    if (type == C2RT_GEOM_CUBE) return cube_intersect<NEED>(G, gid, r, h);
     if constexpr (LEVEL >= 2) {
-        return csg_intersect_call<LEVEL, NEED>(cx, G, o, d, h);
+        return csg_intersect_call<LEVEL, NEED>(cx, G, r, h);
     } else if constexpr (LEVEL == 1) {
-        return csg_intersect<1, NEED>(cx, G, o, d, h);
+        return csg_intersect<1, NEED>(cx, G, r, h);
     } else {
         return false;
     }
@@ -375,6 +436,7 @@ struct RayW {
     D3 o, d;
     D3 dn;      /* d * (1/|d|) */
     double len; /* |d| */
+    double A;   /* |dn|^2 */
 };
 DEV RayW make_ray(D3 o, D3 d)
 {
@@ -384,6 +446,7 @@ DEV RayW make_ray(D3 o, D3 d)
     r.len = mag(d);
     const double inv = 1.0 / r.len;
     r.dn = mk(d.x * inv, d.y * inv, d.z * inv);
+    r.A = sqmag(r.dn);
     return r;
 }
 
@@ -392,29 +455,39 @@ template <int LEVELS, int NEED>
 DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &best)
 {
     const uint32_t flags = N->flags;
-    D3 oc = ray.o, dc;
+    ORay rc;
+    rc.o = ray.o;
     double len;
-    if (!(flags & kNodeZeroOffset)) oc = oc - ld3(N->off);
+    if (!(flags & kNodeZeroOffset)) rc.o = rc.o - ld3(N->off);
     if (flags & kNodeIdentityMatrix) {
-        dc = ray.dn;
+        rc.d = ray.dn;
+        rc.A = ray.A;
         len = ray.len;
     } else {
-        oc = mulvm(oc, N->inv);
+        rc.o = mulvm(rc.o, N->inv);
         const D3 dd = mulvm(ray.d, N->inv);
         len = mag(dd);
         const double inv = 1.0 / len;
-        dc = mk(dd.x * inv, dd.y * inv, dd.z * inv);
+        rc.d = mk(dd.x * inv, dd.y * inv, dd.z * inv);
+        rc.A = sqmag(rc.d);
     }
+    const int gid = N->geom;
+    const DevGeom *G = cx.geoms + gid;
+    /* cubes and CSG trees are expensive to miss: bounding-sphere reject first */
+    if (G->type >= C2RT_GEOM_CUBE && (G->flags & kGeomBounded) && misses_bound(G, rc)) return false;
     Hit h;
     h.dist = best.dist * len;
-    if (!geom_intersect<LEVELS, NEED>(cx, N->geom, oc, dc, h)) return false;
+    if (!geom_intersect<LEVELS, NEED>(cx, gid, rc, h)) return false;
     if (NEED == kBool) return true;
     best.dist = h.dist / len;
     best.g = h.g;
     best.u = h.u;
     best.v = h.v;
+    best.w = h.w;
+    best.uv_pending = h.uv_pending;
     if (flags & kNodeIdentityMatrix) {
-        best.n = normalized(h.n);
+        /* normalize() of an exact unit axis is the identity (sqrt(1) = 1, 1/1 = 1) */
+        best.n = h.axis_n ? h.n : normalized(h.n);
         best.p = h.p;
     } else {
         best.n = normalized(mulvm(h.n, N->tinv));
@@ -593,12 +666,16 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt,
     Hit best;
     best.dist = 1e99;
     best.p = best.n = mk(0, 0, 0);
-    best.u = best.v = 0;
+    best.u = best.v = best.w = 0;
     best.g = -1;
+    best.uv_pending = false;
+    best.axis_n = false;
     int closest = -1;
     const uint32_t nn = P.n_nodes;
     for (uint32_t n = 0; n < nn; ++n)
         if (node_intersect<LEVELS, kFull>(cx, P.nodes + n, ray, best)) closest = (int)n;
+    /* Sphere u,v are read only by textured shaders (and the probe) */
+    if (closest >= 0 && best.uv_pending && (probe || P.shaders[P.nodes[closest].shader].tex >= 0)) finish_uv(best);
     if (probe) {
         probe->closest_node = closest;
         probe->leaf_geom = closest >= 0 ? best.g : -1;

@@ -18,6 +18,7 @@ CONFIGS = {
     "zaphod_215x143_dof25": dict(scene="zaphod.sdl", w=215, h=143, taps=1, dof=1, seed=7),  # as shipped: 25 DOF samples, build RNG
     "csg_stress_320x240_t1": dict(scene="csg_stress.sdl", w=320, h=240, taps=1, dof=0),
     "csg_stress_320x240_t5": dict(scene="csg_stress.sdl", w=320, h=240, taps=5, dof=0),
+    "csg_corner_256x192_t1": dict(scene="csg_corner.sdl", w=256, h=192, taps=1, dof=0),
 }
 
 
