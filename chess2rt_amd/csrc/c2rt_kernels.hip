@@ -29,11 +29,25 @@ namespace c2rt {
 namespace {
 
 #define DEV __device__ __forceinline__
-/* Register budget: measured on MI355X (profiles/), 3 waves/SIMD (168 VGPRs) is
- * the best trade between spills and latency hiding for this fp64 trace; with no
- * hint hipcc takes all 512 registers and runs one wave per SIMD (1.8x slower). */
+
+/* fp64 libm is only reached by a few lanes (sphere u,v, the Phong lobe,
+ * Procedure2) but, inlined, its ~70 live registers set the whole kernel's
+ * budget; as real calls the trace stays under 168 VGPRs without spills. */
+__device__ __noinline__ double c2_pow(double a, double b) { return pow(a, b); }
+__device__ __noinline__ double c2_atan2(double a, double b) { return atan2(a, b); }
+__device__ __noinline__ double c2_asin(double a) { return asin(a); }
+__device__ __noinline__ double c2_sin(double a) { return sin(a); }
+__device__ __noinline__ double c2_cos(double a) { return cos(a); }
+/* Register budget, measured on MI355X (profiles/): with no hint hipcc takes all
+ * 512 registers and runs one wave per SIMD (1.8x slower).  The CSG-free kernel
+ * fits 4 waves/SIMD (128 VGPRs) without spills; the CSG kernels are fastest at
+ * 3 waves/SIMD (168 VGPRs) — at 4 they spill, at 2 latency shows. */
 #ifndef C2RT_OCC
+#if defined(C2RT_UNIT) && C2RT_UNIT == 0
+#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
 #endif
 #ifndef C2RT_XCD_SWIZZLE
 #define C2RT_XCD_SWIZZLE 1
@@ -100,9 +114,9 @@ DEV void finish_uv(Hit &h)
 {
     if (h.uv_pending) {
         constexpr double PI = 3.14159265358979323846;
-        const double angle = atan2(h.v, h.u);
+        const double angle = c2_atan2(h.v, h.u);
         h.u = (PI + angle) / (2 * PI);
-        h.v = 1.0 - (PI / 2 + asin(h.w)) / PI;
+        h.v = 1.0 - (PI / 2 + c2_asin(h.w)) / PI;
         h.uv_pending = false;
     }
 }
@@ -547,8 +561,8 @@ DEV F3 tex_color(const RenderParams &P, int tex, double u, double v)
         F3 result = mkf(0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            result = result + (ldf3(T->color + 3 * i) * (float)sin(u * T->param[i]) +
-                               ldf3(T->color + 9 + 3 * i) * (float)sin(v * T->param[3 + i]));
+            result = result + (ldf3(T->color + 3 * i) * (float)c2_sin(u * T->param[i]) +
+                               ldf3(T->color + 9 + 3 * i) * (float)c2_sin(v * T->param[3 + i]));
         return result;
     } else { /* BitmapTexture.getTexColor — rt/texture.d:116-126 */
         const double s = (double)T->scaling;
@@ -596,7 +610,7 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, int shader, D3 rd, const Hit 
                     const D3 R = normalized(ml - N * (2 * dot(ml, N)));
                     const double cosGamma = dot(R, -rd);
                     if (cosGamma > 0)
-                        avgSpecular = avgSpecular + baseLight * (float)pow(cosGamma, S->exponent) * S->strength;
+                        avgSpecular = avgSpecular + baseLight * (float)c2_pow(cosGamma, S->exponent) * S->strength;
                 }
             }
         }
@@ -642,7 +656,7 @@ DEV void screen_ray(const c2rt_camera_frame &cam, double x, double y, int offset
         constexpr double PI = 3.14159265358979323846;
         const double angle = rng_next(rng) * 2 * PI;
         const double rad = sqrt(rng_next(rng));
-        double dx = sin(angle) * rad, dy = cos(angle) * rad;
+        double dx = c2_sin(angle) * rad, dy = c2_cos(angle) * rad;
         dx *= cam.disc_multiplier;
         dy *= cam.disc_multiplier;
         orig = pos + rightDir * dx + ld3(cam.up_dir) * dy;
