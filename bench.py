@@ -5,12 +5,18 @@ A "step" is one frame: every pixel of the workload traced and shaded by the
 HIP kernel behind the C ABI (scene tables, textures and the frame buffer are
 resident in HBM when the timed region starts).
 
-N=1 workload (default): data/lecture5.sdl at 3840x2160, 1 sample/pixel — the
-configuration BASELINE.json's north_star target is quoted on.
+N=1 workload (default): data/lecture5.sdl at 3840x2160 exactly as the scene
+file ships (AAEnabled: the reference's fixed 5-tap anti-aliasing, Phong +
+shadow rays + bitmap textures + CSG) — the frame BASELINE.json's north_star
+target (>= 1 Gray/s at 4K on one MI355X) is quoted on.  The other BASELINE
+configs (1 tap, 1080p, zaphod, 8K) are measured in the same run and reported
+under config.other_workloads.
 N>1 (one process per GPU, launched by torch.distributed.run): WEAK scaling —
 the frame keeps its 16:9 shape and grows to N x the N=1 pixel count, ranks
-render interleaved 8-row strips and one RCCL gather brings them to rank 0,
-where a copy kernel de-interleaves them.
+render interleaved 8-row strips and one RCCL gather per frame brings them to
+rank 0, where a copy kernel de-interleaves them.
+Frames are double-buffered: the gather of frame i runs on RCCL's stream while
+frame i+1 renders; all K frames are complete inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -29,8 +35,8 @@ SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
 WORKLOADS = {
     # name: (scene file, width, height, taps, dof)
-    "lecture5_4k": ("lecture5.sdl", 3840, 2160, 1, False),       # north_star target config
-    "lecture5_4k_aa5": ("lecture5.sdl", 3840, 2160, 5, False),   # as the scene file ships (AAEnabled)
+    "lecture5_4k_aa5": ("lecture5.sdl", 3840, 2160, 5, False),   # north_star target frame, scene file as shipped (AAEnabled)
+    "lecture5_4k": ("lecture5.sdl", 3840, 2160, 1, False),       # same frame with AAEnabled=false
     "lecture5_1080p": ("lecture5.sdl", 1920, 1080, 1, False),    # BASELINE configs[2]
     "lecture4_1080p": ("lecture4.sdl", 1920, 1080, 1, False),    # BASELINE configs[1]
     "zaphod_4k_4spp": ("zaphod.sdl", 3840, 2160, 4, False),      # BASELINE configs[3], DOF off
@@ -77,12 +83,123 @@ def cpu_baseline(scene, cam, opts, rays_per_frame, budget_s=12.0):
     }
 
 
+class FramePipe:
+    """Per-rank frame producer: render (HIP kernel) -> [gather over RCCL ->
+    de-interleave on rank 0].  With world > 1 and overlap on, frames are
+    double-buffered so that the gather/de-interleave of frame i runs beside
+    the render of frame i+1 (separate streams)."""
+
+    def __init__(self, torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, strip_height, dev, overlap):
+        self.torch, self.dist, self.ctx, self.cam = torch, dist, ctx, cam
+        self.world, self.rank, self.width, self.height = world, rank, width, height
+        self.plan = c2.plan_strips(height, world, strip_height)
+        self.opts = scene.renderOpts(taps=taps, strip_height=self.plan.strip_height, strip_rank=rank, strip_world=world)
+        self.my_rows = ctx.localRows(self.opts)
+        self.stream = torch.cuda.current_stream(dev)
+        self.overlap = overlap and world > 1
+        nbuf = 2 if self.overlap else 1
+        self.local = [torch.zeros((self.plan.rows_pad, width, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        self.gathered = self.frame = None
+        if world > 1 and rank == 0:
+            self.gathered = [torch.empty((world, self.plan.rows_pad, width, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+            self.frame = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
+        self.side = torch.cuda.Stream(dev) if self.overlap else None
+        self.work = [None] * nbuf       # outstanding gather per buffer
+        self.post = [None] * nbuf       # event: rank 0 finished reading gathered[b]
+        self.i = 0
+
+    def render(self, b, events=None):
+        if events:
+            events[0].record(self.stream)
+        self.ctx.renderFrameDevice(self.cam, self.opts, self.local[b].data_ptr(), self.stream.cuda_stream)
+        if events:
+            events[1].record(self.stream)
+
+    def _deinterleave(self, b, stream):
+        self.ctx.deinterleaveStrips(self.gathered[b].data_ptr(), self.frame.data_ptr(), self.width, self.height,
+                                    self.plan.strip_height, self.world, stream.cuda_stream)
+
+    def step(self, events=None):
+        torch, dist = self.torch, self.dist
+        if self.world == 1:
+            self.render(0, events)
+            return
+        if not self.overlap:
+            self.render(0, events)
+            if self.rank == 0:
+                dist.gather(self.local[0], list(self.gathered[0].unbind(0)), dst=0)
+                self._deinterleave(0, self.stream)
+            else:
+                dist.gather(self.local[0], None, dst=0)
+            return
+        b = self.i % 2
+        self.i += 1
+        if self.work[b] is not None:
+            self.work[b].wait()                       # the gather that read local[b] two frames ago is done
+        self.render(b, events)
+        if self.rank == 0:
+            if self.post[b] is not None:
+                self.stream.wait_event(self.post[b])  # gathered[b] was consumed by the previous de-interleave
+            self.work[b] = dist.gather(self.local[b], list(self.gathered[b].unbind(0)), dst=0, async_op=True)
+            with torch.cuda.stream(self.side):
+                self.work[b].wait()                   # side stream waits for RCCL
+                self._deinterleave(b, self.side)
+                self.post[b] = torch.cuda.Event()
+                self.post[b].record(self.side)
+        else:
+            self.work[b] = dist.gather(self.local[b], None, dst=0, async_op=True)
+
+    def drain(self):
+        for w in self.work:
+            if w is not None:
+                w.wait()
+        if self.side is not None:
+            self.stream.wait_stream(self.side)
+
+
+def measure(torch, dist, pipe, steps, warmup, world, dev):
+    """W untimed + exactly K timed steps between barriers; max over ranks."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        pipe.step()
+    pipe.drain()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pipe.step(ev[i])
+    pipe.drain()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    kernel_ms = statistics.mean(a.elapsed_time(b) for a, b in ev)
+    return float(el.item()), kernel_ms
+
+
+def count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev):
+    copts = scene.renderOpts(taps=taps, strip_height=pipe.plan.strip_height, strip_rank=rank, strip_world=world, count_rays=1)
+    ctx.renderFrameDevice(cam, copts, pipe.local[0].data_ptr(), pipe.stream.cuda_stream)
+    primary, shadow = ctx.rayStats()
+    rays = torch.tensor([primary, shadow], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays)
+    return int(rays[0].item()), int(rays[1].item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="lecture5_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="lecture5_4k_aa5", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for each gather before rendering the next frame")
+    ap.add_argument("--no-others", action="store_true", help="N=1: skip the other BASELINE configs")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strip-height", type=int, default=8)
@@ -106,88 +223,51 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    scene_file, w0, h0, taps, dof = WORKLOADS[args.workload]
-    width, height = (weak_frame(w0, h0, world) if args.scaling == "weak" else (w0, h0))
-    scene = c2.parseSceneFromFile(os.path.join(SCENES, scene_file))
-    scene.setFrameSize(width, height)
-    scene.setDof(dof)
-    cam = scene.beginFrame()
-
     ctx = c2.Context(local_rank)
-    ctx.uploadScene(scene.desc)
-    plan = c2.plan_strips(height, world, args.strip_height)
-    opts = scene.renderOpts(taps=taps, strip_height=plan.strip_height, strip_rank=rank, strip_world=world)
-    my_rows = ctx.localRows(opts)
 
-    stream = torch.cuda.current_stream(dev)
-    local = torch.zeros((plan.rows_pad, width, 3), dtype=torch.float32, device=dev)
-    gathered = frame = None
-    if world > 1 and rank == 0:
-        gathered = torch.empty((world, plan.rows_pad, width, 3), dtype=torch.float32, device=dev)
-        frame = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
+    def run(workload, steps, warmup):
+        scene_file, w0, h0, taps, dof = WORKLOADS[workload]
+        width, height = (weak_frame(w0, h0, world) if args.scaling == "weak" else (w0, h0))
+        scene = c2.parseSceneFromFile(os.path.join(SCENES, scene_file))
+        scene.setFrameSize(width, height)
+        scene.setDof(dof)
+        cam = scene.beginFrame()
+        ctx.uploadScene(scene.desc)
+        pipe = FramePipe(torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, args.strip_height, dev,
+                         not args.no_overlap)
+        primary, shadow = count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev)
+        elapsed, kernel_ms = measure(torch, dist, pipe, steps, warmup, world, dev)
+        return dict(scene=scene, cam=cam, pipe=pipe, scene_file=scene_file, width=width, height=height, taps=taps,
+                    primary=primary, shadow=shadow, elapsed=elapsed, kernel_ms=kernel_ms, steps=steps)
 
-    def step():
-        ctx.renderFrameDevice(cam, opts, local.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            if rank == 0:
-                dist.gather(local, list(gathered.unbind(0)), dst=0)
-                ctx.deinterleaveStrips(gathered.data_ptr(), frame.data_ptr(), width, height, plan.strip_height, world,
-                                       stream.cuda_stream)
-            else:
-                dist.gather(local, None, dst=0)
+    r = run(args.workload, args.steps, args.warmup)
 
-    # rays per frame (deterministic): one untimed counting pass
-    copts = scene.renderOpts(taps=taps, strip_height=plan.strip_height, strip_rank=rank, strip_world=world, count_rays=1)
-    ctx.renderFrameDevice(cam, copts, local.data_ptr(), stream.cuda_stream)
-    primary, shadow = ctx.rayStats()
-    rays = torch.tensor([primary, shadow], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(rays)
-    primary, shadow = int(rays[0].item()), int(rays[1].item())
-    rays_per_frame = primary + shadow
-
-    for _ in range(args.warmup):
-        step()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # kernel-only duration: events on the launch stream around each render launch
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev0[i].record(stream)
-        ctx.renderFrameDevice(cam, opts, local.data_ptr(), stream.cuda_stream)
-        ev1[i].record(stream)
-        if world > 1:
-            if rank == 0:
-                dist.gather(local, list(gathered.unbind(0)), dst=0)
-                ctx.deinterleaveStrips(gathered.data_ptr(), frame.data_ptr(), width, height, plan.strip_height, world,
-                                       stream.cuda_stream)
-            else:
-                dist.gather(local, None, dst=0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    kernel_ms = statistics.mean(a.elapsed_time(b) for a, b in zip(ev0, ev1))
+    others = {}
+    if world == 1 and not args.no_others:
+        for name in WORKLOADS:
+            if name == args.workload:
+                continue
+            o = run(name, min(args.steps, 20), min(args.warmup, 3))
+            rays = o["primary"] + o["shadow"]
+            others[name] = {
+                "workload": "%s %dx%d, %d tap(s)" % (o["scene_file"], o["width"], o["height"], o["taps"]),
+                "Mray_per_s": rays * o["steps"] / o["elapsed"] / 1e6,
+                "ms_per_frame": o["elapsed"] / o["steps"] * 1e3,
+                "kernel_ms": o["kernel_ms"],
+                "rays_per_frame": rays,
+            }
+        # leave the context on the headline scene for the CPU baseline below
+        ctx.uploadScene(r["scene"].desc)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = rays_per_frame * args.steps / elapsed / 1e6
+        scene, pipe = r["scene"], r["pipe"]
+        rays_per_frame = r["primary"] + r["shadow"]
+        ms_per_step = r["elapsed"] / r["steps"] * 1e3
+        value = rays_per_frame * r["steps"] / r["elapsed"] / 1e6
         # algorithmic HBM bytes of one launch: 12 B per pixel written + every bitmap texel once
-        d = scene.desc.contents
-        tex_bytes = int(d.n_texels) * 12
-        alg_bytes = my_rows * width * 12 + tex_bytes
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        tex_bytes = int(scene.desc.contents.n_texels) * 12
+        alg_bytes = pipe.my_rows * r["width"] * 12 + tex_bytes
+        achieved = alg_bytes / (r["kernel_ms"] * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if world == 1 and os.path.exists(prof):
@@ -200,24 +280,27 @@ def main():
             "value": value,
             "unit": "Mray/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": r["steps"],
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic: the reference's own scene file and textures (tests/golden/scenes), no camera motion",
+            "data": "synthetic: the reference's own scene file and textures (tests/golden/scenes), fixed camera",
             "config": {
-                "workload": "%s %dx%d, %d tap(s)/pixel, dof off%s" % (
-                    scene_file, width, height, taps,
-                    "" if world == 1 else "; %d interleaved %d-row strip sets + RCCL gather to rank 0" % (world, plan.strip_height)),
+                "workload": "%s %dx%d, %d tap(s)/pixel%s, dof off%s" % (
+                    r["scene_file"], r["width"], r["height"], r["taps"],
+                    " (AAEnabled as shipped: reference 5-tap AA)" if r["taps"] == 5 else "",
+                    "" if world == 1 else "; %d ranks x interleaved %d-row strips + RCCL gather to rank 0 (%s)" % (
+                        world, pipe.plan.strip_height, "double-buffered" if pipe.overlap else "serial")),
                 "name": args.workload,
-                "primary_rays_per_frame": primary,
-                "shadow_rays_per_frame": shadow,
-                "Msample_per_s": primary * args.steps / elapsed / 1e6,
-                "frames_per_s": args.steps / elapsed,
-                "kernel_ms_rank0": kernel_ms,
+                "primary_rays_per_frame": r["primary"],
+                "shadow_rays_per_frame": r["shadow"],
+                "Msample_per_s": r["primary"] * r["steps"] / r["elapsed"] / 1e6,
+                "frames_per_s": r["steps"] / r["elapsed"],
+                "kernel_ms_rank0": r["kernel_ms"],
+                "other_workloads": others,
             },
             "roofline": {
                 "bound": "hbm",
@@ -227,13 +310,13 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_ms": kernel_ms,
-                "note": "the path is fp64-VALU bound, not HBM bound (DESIGN.md): 12 B/pixel is all it must move",
+                "kernel_ms": r["kernel_ms"],
+                "note": "by the numbers this path is fp64-VALU bound, not HBM bound (DESIGN.md 4.1): 12 B/pixel is all it must move",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            full = scene.renderOpts(taps=taps)
-            out["cpu_baseline"] = cpu_baseline(scene, cam, full, rays_per_frame)
+            full = scene.renderOpts(taps=r["taps"])
+            out["cpu_baseline"] = cpu_baseline(scene, r["cam"], full, rays_per_frame)
         print(json.dumps(out), flush=True)
 
     if world > 1:
