@@ -435,6 +435,7 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         if (depth > C2RT_MAX_CSG_DEPTH) return fail(ctx, C2RT_ERR_LIMIT, "node %u: CSG nesting %d > %d", n, depth, C2RT_MAX_CSG_DEPTH);
         if (depth > levels) levels = depth;
         bound_of(s, d.geom, bounds, geoms);
+        d.g = geoms[d.geom]; /* after bound_of: carries the flags and the bound */
         const double *t = s->node_transform + 30 * (size_t)n;
         std::memcpy(d.m, t, 9 * sizeof(double));
         std::memcpy(d.inv, t + 9, 9 * sizeof(double));

@@ -58,13 +58,16 @@ enum NodeFlags : uint32_t {
     kNodeZeroOffset = 2u,          /* offset == 0: skip the subtraction/addition */
 };
 
-struct alignas(16) DevNode {       /* 256 B */
+struct alignas(16) DevNode {       /* 336 B; the first 112 B are all a primitive under an identity matrix needs */
     int32_t geom, shader;
     uint32_t flags, pad;
+    double off[3];
+    double pad2;
+    DevGeom g;                     /* copy of geoms[geom]: one scalar load instead of a dependent pair */
     double inv[9];                 /* inverseTransform */
     double m[9];                   /* transform */
     double tinv[9];                /* transposedInverse */
-    double off[3];
+    double pad3;
 };
 
 struct alignas(16) DevShader {     /* 32 B */

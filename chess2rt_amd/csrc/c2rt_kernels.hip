@@ -423,9 +423,8 @@ __device__ __noinline__ bool csg_intersect_call(const Ctx &cx, const DevGeom *G,
 
 /* Geometry.intersect: `gid` is wave-uniform, so this is a scalar branch. */
 template <int LEVEL, int NEED>
-__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h)
+__device__ __forceinline__ bool geom_intersect_rec(const Ctx &cx, const DevGeom *G, int gid, const ORay &r, Hit &h)
 {
-    const DevGeom *G = cx.geoms + gid;
     const int type = G->type;
     if (type == C2RT_GEOM_PLANE) return plane_intersect<NEED>(G, gid, r, h);
     if (type == C2RT_GEOM_SPHERE) return sphere_intersect<NEED>(G, gid, r, h);
@@ -437,6 +436,12 @@ __device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORa
     } else {
         return false;
     }
+}
+
+template <int LEVEL, int NEED>
+__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h)
+{
+    return geom_intersect_rec<LEVEL, NEED>(cx, cx.geoms + gid, gid, r, h);
 }
 
 /* ------------------------------------------------------------------ */
@@ -486,12 +491,12 @@ DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &b
         rc.A = sqmag(rc.d);
     }
     const int gid = N->geom;
-    const DevGeom *G = cx.geoms + gid;
+    const DevGeom *G = &N->g; /* the node's own copy of its root geometry record */
     /* cubes and CSG trees are expensive to miss: bounding-sphere reject first */
     if (G->type >= C2RT_GEOM_CUBE && (G->flags & kGeomBounded) && misses_bound(G, rc)) return false;
     Hit h;
     h.dist = best.dist * len;
-    if (!geom_intersect<LEVELS, NEED>(cx, gid, rc, h)) return false;
+    if (!geom_intersect_rec<LEVELS, NEED>(cx, G, gid, rc, h)) return false;
     if (NEED == kBool) return true;
     best.dist = h.dist / len;
     best.g = h.g;
