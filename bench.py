@@ -89,8 +89,10 @@ class FramePipe:
     double-buffered so that the gather/de-interleave of frame i runs beside
     the render of frame i+1 (separate streams)."""
 
-    def __init__(self, torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, strip_height, dev, overlap):
+    def __init__(self, torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, strip_height, dev, overlap,
+                 backend="nccl"):
         self.torch, self.dist, self.ctx, self.cam = torch, dist, ctx, cam
+        self.backend = backend
         self.world, self.rank, self.width, self.height = world, rank, width, height
         self.plan = c2.plan_strips(height, world, strip_height)
         self.opts = scene.renderOpts(taps=taps, strip_height=self.plan.strip_height, strip_rank=rank, strip_world=world)
@@ -104,6 +106,11 @@ class FramePipe:
             self.gathered = [torch.empty((world, self.plan.rows_pad, width, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
             self.frame = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
         self.side = torch.cuda.Stream(dev) if self.overlap else None
+        self.cpu_stage = self.cpu_list = None
+        if backend == "gloo" and world > 1:   # rehearsal only: gloo gathers host tensors
+            self.cpu_stage = [torch.empty((self.plan.rows_pad, width, 3), dtype=torch.float32) for _ in range(nbuf)]
+            if rank == 0:
+                self.cpu_list = [[torch.empty((self.plan.rows_pad, width, 3), dtype=torch.float32) for _ in range(world)] for _ in range(nbuf)]
         self.work = [None] * nbuf       # outstanding gather per buffer
         self.post = [None] * nbuf       # event: rank 0 finished reading gathered[b]
         self.i = 0
@@ -114,6 +121,20 @@ class FramePipe:
         self.ctx.renderFrameDevice(self.cam, self.opts, self.local[b].data_ptr(), self.stream.cuda_stream)
         if events:
             events[1].record(self.stream)
+
+    def _gather(self, b, async_op):
+        """One gather of local[b] to rank 0 (RCCL over xGMI; `gloo` = host-staged rehearsal)."""
+        dist = self.dist
+        if self.backend == "gloo":
+            self.stream.synchronize()
+            self.cpu_stage[b].copy_(self.local[b])
+            return dist.gather(self.cpu_stage[b], self.cpu_list[b] if self.rank == 0 else None, dst=0, async_op=async_op)
+        return dist.gather(self.local[b], list(self.gathered[b].unbind(0)) if self.rank == 0 else None, dst=0, async_op=async_op)
+
+    def _landed(self, b):
+        if self.backend == "gloo" and self.rank == 0:
+            for r in range(self.world):
+                self.gathered[b][r].copy_(self.cpu_list[b][r])
 
     def _deinterleave(self, b, stream):
         self.ctx.deinterleaveStrips(self.gathered[b].data_ptr(), self.frame.data_ptr(), self.width, self.height,
@@ -126,11 +147,10 @@ class FramePipe:
             return
         if not self.overlap:
             self.render(0, events)
+            self._gather(0, False)
             if self.rank == 0:
-                dist.gather(self.local[0], list(self.gathered[0].unbind(0)), dst=0)
+                self._landed(0)
                 self._deinterleave(0, self.stream)
-            else:
-                dist.gather(self.local[0], None, dst=0)
             return
         b = self.i % 2
         self.i += 1
@@ -140,14 +160,15 @@ class FramePipe:
         if self.rank == 0:
             if self.post[b] is not None:
                 self.stream.wait_event(self.post[b])  # gathered[b] was consumed by the previous de-interleave
-            self.work[b] = dist.gather(self.local[b], list(self.gathered[b].unbind(0)), dst=0, async_op=True)
+            self.work[b] = self._gather(b, True)
             with torch.cuda.stream(self.side):
                 self.work[b].wait()                   # side stream waits for RCCL
+                self._landed(b)
                 self._deinterleave(b, self.side)
                 self.post[b] = torch.cuda.Event()
                 self.post[b].record(self.side)
         else:
-            self.work[b] = dist.gather(self.local[b], None, dst=0, async_op=True)
+            self.work[b] = self._gather(b, True)
 
     def drain(self):
         for w in self.work:
@@ -203,6 +224,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strip-height", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = single-GPU rehearsal of the N>1 flow: host-staged gather, every rank on device 0")
+    ap.add_argument("--check", action="store_true", help="N>1: compare the gathered frame with a single-rank render (bit-exact)")
     args = ap.parse_args()
 
     import torch
@@ -217,11 +241,16 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the render path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     ctx = c2.Context(local_rank)
 
@@ -234,13 +263,23 @@ def main():
         cam = scene.beginFrame()
         ctx.uploadScene(scene.desc)
         pipe = FramePipe(torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, args.strip_height, dev,
-                         not args.no_overlap)
+                         not args.no_overlap, args.backend)
         primary, shadow = count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev)
         elapsed, kernel_ms = measure(torch, dist, pipe, steps, warmup, world, dev)
         return dict(scene=scene, cam=cam, pipe=pipe, scene_file=scene_file, width=width, height=height, taps=taps,
                     primary=primary, shadow=shadow, elapsed=elapsed, kernel_ms=kernel_ms, steps=steps)
 
     r = run(args.workload, args.steps, args.warmup)
+
+    if args.check and world > 1 and rank == 0:
+        # the gathered + de-interleaved frame must equal a whole-frame render bit for bit
+        pipe = r["pipe"]
+        whole = torch.empty((r["height"], r["width"], 3), dtype=torch.float32, device=dev)
+        ctx.renderFrameDevice(r["cam"], r["scene"].renderOpts(taps=r["taps"]), whole.data_ptr(), pipe.stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        if not torch.equal(whole, pipe.frame):
+            raise SystemExit("bench.py --check: gathered frame differs from the single-rank frame")
+        print("bench.py --check: gathered frame == single-rank frame (bit-exact)", file=sys.stderr)
 
     others = {}
     if world == 1 and not args.no_others:
