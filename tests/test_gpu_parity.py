@@ -272,3 +272,73 @@ def test_csg_depth_limit_and_cycles_are_rejected(gpu_ctx):
     with pytest.raises(c2.C2rtError) as e:
         gpu_ctx.uploadScene(d)
     assert e.value.status == _abi.ERR_INVALID_ARG
+
+
+def _load_text(tmp_path, text, name="s.sdl"):
+    p = tmp_path / name
+    p.write_text(text)
+    return c2.parseSceneFromFile(str(p))
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (8, 8), (9, 17), (64, 1), (1, 70)])
+def test_edge_frame_sizes(w, h, gpu_ctx):
+    scene, _, _ = load_config("lecture5_640x480_t1")
+    scene.setFrameSize(w, h)
+    cam = scene.beginFrame()
+    for taps in (1, 5):
+        opts = scene.renderOpts(taps=taps)
+        gpu_ctx.uploadScene(scene.desc)
+        a = gpu_ctx.renderFrame(cam, opts)
+        ref = orc.render_frame(scene.desc, cam, opts, 1)
+        assert a.shape == (h, w, 3) and maxdiff(a, ref)[0] <= TOL
+
+
+def test_empty_and_degenerate_scenes(gpu_ctx, tmp_path):
+    cases = {
+        # no nodes at all: every ray returns the (black) environment
+        "empty": 'Scene { Camera { pos 0 1 0; fov 90 } }',
+        # geometry but no lights: ambient only
+        "nolight": '''Scene { GlobalSettings { ambientLightColor 0.3 0.2 0.1 }
+            Camera { pos 0 5 -10; pitch -20; fov 80 }
+            Geometries { Plane "p" { y 0 }; Sphere "s" { center 0 2 5; R 2 } }
+            Shaders { Lambert "l" { color 0.5 0.5 0.5 } }
+            Nodes { Node "a" { geometry "p"; shader "l" }; Node "b" { geometry "s"; shader "l" } } }''',
+        # a light whose colour * power has zero intensity casts no shadow ray (rt/shader.d:88)
+        "darklight": '''Scene { Camera { pos 0 5 -10; pitch -20; fov 80 }
+            Lights { PointLight "z" { pos 0 10 0; color 0 0 0; power 100 }; PointLight "n" { pos 3 10 0; color 1 1 1; power 0 } }
+            Geometries { Plane "p" { y 0 } }
+            Shaders { Phong "l" { color 0.5 0.5 0.5 } }
+            Nodes { Node "a" { geometry "p"; shader "l" } } }''',
+        # Plane() without y: y is NaN, every comparison fails -> never... (reference semantics, whatever they are)
+        "nanplane": '''Scene { Camera { pos 0 5 -10; pitch -20; fov 80 }
+            Lights { PointLight "k" { pos 0 10 0; color 1 1 1; power 500 } }
+            Geometries { Plane "p" { }; Cube "c" { center 0 1 4; side 2 } }
+            Shaders { Lambert "l" { } }
+            Nodes { Node "a" { geometry "p"; shader "l" }; Node "b" { geometry "c"; shader "l"; scale 1 0 1 } } }''',
+        # far-away geometry and huge texture coordinates (cast(int) overflow path of Checker)
+        "huge": '''Scene { Camera { pos 0 1e7 0; pitch -89; fov 120 }
+            Lights { PointLight "k" { pos 0 2e7 0; color 1 1 1; power 1e16 } }
+            Geometries { Plane "p" { y 0 } }
+            Textures { Checker "c" { color1 1 0 0; color2 0 1 0; size 0.001 } }
+            Shaders { Lambert "l" { texture "c" } }
+            Nodes { Node "a" { geometry "p"; shader "l" } } }''',
+    }
+    for name, text in cases.items():
+        scene = _load_text(tmp_path, text, name + ".sdl")
+        scene.setFrameSize(96, 64)
+        scene.setAA(False)
+        cam = scene.beginFrame()
+        opts = scene.renderOpts(count_rays=1)
+        gpu_ctx.uploadScene(scene.desc)
+        a = gpu_ctx.renderFrame(cam, opts)
+        pr, sh = gpu_ctx.rayStats()
+        st = {}
+        ref = orc.render_frame(scene.desc, cam, opts, 1, st)
+        md, nbad, _ = maxdiff(a, ref)
+        assert np.array_equal(np.isnan(a), np.isnan(ref)), name
+        assert md <= TOL and nbad == 0, (name, md)
+        assert (pr, sh) == (st["primary"], st["shadow"]), name
+        if name == "empty":
+            assert not a.any() and sh == 0
+        if name == "darklight":
+            assert sh == 0
