@@ -40,6 +40,7 @@ WORKLOADS = {
     "lecture5_1080p": ("lecture5.sdl", 1920, 1080, 1, False),    # BASELINE configs[2]
     "lecture4_1080p": ("lecture4.sdl", 1920, 1080, 1, False),    # BASELINE configs[1]
     "zaphod_4k_4spp": ("zaphod.sdl", 3840, 2160, 4, False),      # BASELINE configs[3], DOF off
+    "zaphod_4k_dof25": ("zaphod.sdl", 3840, 2160, 1, True),      # zaphod.sdl as shipped: 25 DOF samples/pixel, build RNG
     "lecture5_8k_4spp": ("lecture5.sdl", 7680, 4320, 4, False),  # BASELINE configs[4] (per-frame size)
 }
 
@@ -289,7 +290,8 @@ def main():
             o = run(name, min(args.steps, 20), min(args.warmup, 3))
             rays = o["primary"] + o["shadow"]
             others[name] = {
-                "workload": "%s %dx%d, %d tap(s)" % (o["scene_file"], o["width"], o["height"], o["taps"]),
+                "workload": "%s %dx%d, %d tap(s)%s" % (o["scene_file"], o["width"], o["height"], o["taps"],
+                                                       ", dof on (%d lens samples)" % o["cam"].num_samples if o["cam"].dof else ""),
                 "Mray_per_s": rays * o["steps"] / o["elapsed"] / 1e6,
                 "ms_per_frame": o["elapsed"] / o["steps"] * 1e3,
                 "kernel_ms": o["kernel_ms"],
