@@ -165,6 +165,8 @@ C2RT_SYMBOLS = {
     "c2rt_local_rows": (C.c_uint32, [_OPTS_P]),
     "c2rt_render_frame": (C.c_int, [_VP, _CAM_P, _OPTS_P, _VP, _VP]),
     "c2rt_render_frame_device": (C.c_int, [_VP, _CAM_P, _OPTS_P, _VP, _VP]),
+    "c2rt_pin_host_buffer": (C.c_int, [_VP, _VP, C.c_size_t]),
+    "c2rt_unpin_host_buffer": (C.c_int, [_VP, _VP]),
     "c2rt_get_ray_stats": (C.c_int, [_VP, C.POINTER(RayStats)]),
     "c2rt_render_pixel": (C.c_int, [_VP, _CAM_P, _OPTS_P, C.c_int, C.c_int, C.POINTER(TraceResult)]),
     "c2rt_deinterleave_strips": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),

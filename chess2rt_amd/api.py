@@ -160,6 +160,19 @@ class Context:
         self._check(self._lib.c2rt_render_frame(self._h, C.byref(cam), C.byref(opts), out.ctypes.data_as(C.c_void_p), stop))
         return out
 
+    def renderFrameInto(self, cam, opts, out, stop_flag=None):
+        """Blocking render into a caller-owned float32 array (e.g. one pinned with pinHostBuffer)."""
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.size >= self.localRows(opts) * opts.width * 3
+        stop = stop_flag.ctypes.data_as(C.c_void_p) if stop_flag is not None else None
+        self._check(self._lib.c2rt_render_frame(self._h, C.byref(cam), C.byref(opts), out.ctypes.data_as(C.c_void_p), stop))
+        return out
+
+    def pinHostBuffer(self, arr):
+        self._check(self._lib.c2rt_pin_host_buffer(self._h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def unpinHostBuffer(self, arr):
+        self._check(self._lib.c2rt_unpin_host_buffer(self._h, arr.ctypes.data_as(C.c_void_p)))
+
     def renderFrameDevice(self, cam, opts, out_ptr, stream=0):
         """Enqueue a render into device memory (e.g. tensor.data_ptr())."""
         self._check(self._lib.c2rt_render_frame_device(self._h, C.byref(cam), C.byref(opts), C.c_void_p(out_ptr), C.c_void_p(stream)))

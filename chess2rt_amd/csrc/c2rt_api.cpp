@@ -13,16 +13,22 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "c2rt_device.h"
 
 using namespace c2rt;
 
+constexpr int kMaxChunks = 8;      /* row chunks of a host-output frame */
+
 struct c2rt_ctx {
     int device = 0;
     std::string err;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;              /* D2H of finished chunks */
+    hipEvent_t chunk_done[kMaxChunks] = {};
+    std::vector<std::pair<float *, size_t>> pinned; /* c2rt_pin_host_buffer */
 
     bool has_scene = false;
     int csg_levels = 0;
@@ -307,6 +313,8 @@ int c2rt_init(int device, c2rt_ctx **out)
     *out = ctx; /* handed out even on failure below so that c2rt_last_error works */
     HIP_TRY(ctx, hipSetDevice(device));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < kMaxChunks; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chunk_done[i], hipEventDisableTiming));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counters), 2 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->probe), sizeof(c2rt_trace_result)));
     uint8_t lut[4097];
@@ -321,6 +329,10 @@ void c2rt_destroy(c2rt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    for (hipEvent_t e : ctx->chunk_done)
+        if (e) (void)hipEventDestroy(e);
+    for (const auto &pb : ctx->pinned) (void)hipHostUnregister(pb.first);
     void *bufs[] = {ctx->geoms, ctx->nodes, ctx->shaders, ctx->textures, ctx->lights, ctx->texels,
                     ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut};
     for (void *b : bufs)
@@ -497,11 +509,78 @@ int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->frame), floats * sizeof(float)));
         ctx->frame_floats = floats;
     }
-    st = render_device(ctx, cam, opts, ctx->frame, ctx->stream);
-    if (st != C2RT_OK) return st;
-    if (floats) HIP_TRY(ctx, hipMemcpyAsync(out_rgb, ctx->frame, floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    /* Into a pinned buffer the frame is rendered in up to 8 row chunks: chunk i
+     * streams back over PCIe (copy stream) while chunk i+1 renders, and the
+     * stop flag is polled between chunks (finer than the reference's
+     * between-pass polling).  Into pageable memory: one launch, one copy. */
+    RenderParams p;
+    fill_params(ctx, cam, opts, p);
+    p.out = ctx->frame;
+    ctx->counters_valid = false;
+    if (opts->count_rays) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        p.ray_counters = ctx->counters;
+    }
+    const uint32_t rows = p.local_rows;
+    /* chunking only pays when the copies are truly asynchronous, i.e. the
+     * destination was page-locked with c2rt_pin_host_buffer (measured: chunked
+     * copies into pageable memory are slower than one copy) */
+    bool is_pinned = false;
+    for (const auto &pb : ctx->pinned)
+        is_pinned = is_pinned || (out_rgb >= pb.first && reinterpret_cast<char *>(out_rgb) + floats * sizeof(float) <=
+                                                             reinterpret_cast<char *>(pb.first) + pb.second);
+    uint32_t chunk = is_pinned ? ((rows + 7) / 8 + kTileH - 1) / kTileH * kTileH : rows;
+    if (chunk < 64) chunk = 64;
+    const KernelVariant variant = variant_of(ctx, cam);
+    const size_t row_floats = (size_t)opts->width * 3;
+    bool cancelled = false;
+    int n_chunks = 0;
+    for (uint32_t off = 0; off < rows && n_chunks < kMaxChunks; off += chunk, ++n_chunks) {
+        if (stop_flag && *stop_flag) { cancelled = true; break; }
+        p.row_offset = off;
+        p.local_rows = rows - off < chunk ? rows - off : chunk;
+        p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
+        const int e = launch_render(p, variant, ctx->stream);
+        if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
+        HIP_TRY(ctx, hipEventRecord(ctx->chunk_done[n_chunks], ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_done[n_chunks], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(out_rgb + off * row_floats, ctx->frame + off * row_floats,
+                                    (size_t)p.local_rows * row_floats * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (cancelled) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested during the frame");
+    if (opts->count_rays) {
+        ctx->counters_valid = true;
+        ctx->counters_stream = ctx->stream;
+    }
     return C2RT_OK;
+}
+
+int c2rt_pin_host_buffer(c2rt_ctx *ctx, float *out_rgb, size_t bytes)
+{
+    if (!ctx) return C2RT_ERR_INVALID_ARG;
+    if (!out_rgb || bytes == 0) return fail(ctx, C2RT_ERR_INVALID_ARG, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (const auto &pb : ctx->pinned)
+        if (pb.first == out_rgb) return C2RT_OK;
+    HIP_TRY(ctx, hipHostRegister(out_rgb, bytes, hipHostRegisterDefault));
+    ctx->pinned.emplace_back(out_rgb, bytes);
+    return C2RT_OK;
+}
+
+int c2rt_unpin_host_buffer(c2rt_ctx *ctx, float *out_rgb)
+{
+    if (!ctx) return C2RT_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (size_t i = 0; i < ctx->pinned.size(); ++i)
+        if (ctx->pinned[i].first == out_rgb) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+            HIP_TRY(ctx, hipHostUnregister(out_rgb));
+            ctx->pinned.erase(ctx->pinned.begin() + (long)i);
+            return C2RT_OK;
+        }
+    return fail(ctx, C2RT_ERR_INVALID_ARG, "buffer was not pinned through this context");
 }
 
 int c2rt_get_ray_stats(c2rt_ctx *ctx, c2rt_ray_stats *out)

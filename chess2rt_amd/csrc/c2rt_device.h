@@ -111,7 +111,8 @@ struct RenderParams {
     uint32_t width, height;        /* frame */
     uint32_t taps;
     uint32_t strip_height, strip_rank, strip_world;
-    uint32_t local_rows;
+    uint32_t local_rows;           /* rows this launch renders */
+    uint32_t row_offset;           /* first local row of this launch (chunked host-output renders) */
     uint32_t tiles_x, tiles_y;     /* tile grid over the LOCAL rows */
     uint32_t blocks_x;             /* ceil(tiles_x / kWavesPerBlock) */
     uint64_t seed;

@@ -238,6 +238,14 @@ int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam,
                       const c2rt_render_opts *opts, float *out_rgb,
                       const volatile uint8_t *stop_flag);
 
+/* Optional: declare a long-lived host frame buffer (the GUI's `screen`,
+ * gui/raytracer_demo.d:181-182) so that c2rt_render_frame can page-lock it once
+ * and stream the frame back at PCIe rate while later rows are still rendering.
+ * The caller must unpin before freeing the buffer.  Without it
+ * c2rt_render_frame copies into pageable memory (slower, same result). */
+int c2rt_pin_host_buffer(c2rt_ctx *ctx, float *out_rgb, size_t bytes);
+int c2rt_unpin_host_buffer(c2rt_ctx *ctx, float *out_rgb);
+
 /* Same, but the output stays in HBM: `out_rgb_dev` is a device pointer
  * (e.g. a torch tensor's data_ptr) and the kernels are enqueued on
  * `hip_stream` (a hipStream_t, NULL = default stream) without a host sync. */

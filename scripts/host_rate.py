@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import chess2rt_amd as c2
 ctx = c2.Context(0)
+import numpy as np
 s = c2.parseSceneFromFile(os.path.join(ROOT, "tests/golden/scenes/lecture5.sdl"))
 for (w, h, taps) in [(3840, 2160, 5), (3840, 2160, 1), (1920, 1080, 1)]:
     s.setFrameSize(w, h)
@@ -16,3 +17,12 @@ for (w, h, taps) in [(3840, 2160, 5), (3840, 2160, 1), (1920, 1080, 1)]:
         ctx.renderFrame(cam, opts)
     dt = (time.perf_counter() - t) / n
     print("lecture5 %dx%d %d tap(s): host-output %.3f ms/frame, %.0f Mray/s (kernel + D2H of %.1f MB into pageable memory)" % (w, h, taps, dt * 1e3, (pr + sh) / dt / 1e6, w * h * 12 / 1e6))
+    out = np.empty((h, w, 3), np.float32)
+    ctx.pinHostBuffer(out)
+    ctx.renderFrameInto(cam, opts, out)
+    t = time.perf_counter()
+    for _ in range(n):
+        ctx.renderFrameInto(cam, opts, out)
+    dt = (time.perf_counter() - t) / n
+    ctx.unpinHostBuffer(out)
+    print("    same into a buffer pinned with c2rt_pin_host_buffer: %.3f ms/frame, %.0f Mray/s" % (dt * 1e3, (pr + sh) / dt / 1e6))

@@ -342,3 +342,27 @@ def test_empty_and_degenerate_scenes(gpu_ctx, tmp_path):
             assert not a.any() and sh == 0
         if name == "darklight":
             assert sh == 0
+
+
+def test_host_output_chunks_pinned_buffer_and_midframe_cancel(gpu_ctx):
+    """c2rt_render_frame renders in row chunks that stream back while later
+    chunks render; a pinned caller buffer and a pageable one get the same bits."""
+    scene, cam, opts = load_config("lecture5_640x480_t5")
+    gpu_ctx.uploadScene(scene.desc)
+    a = gpu_ctx.renderFrame(cam, opts)                       # pageable numpy buffer
+    ref = orc.render_frame(scene.desc, cam, opts, 0)
+    assert maxdiff(a, ref)[0] <= TOL
+    out = np.full((opts.height, opts.width, 3), -1.0, np.float32)
+    gpu_ctx.pinHostBuffer(out)
+    gpu_ctx.pinHostBuffer(out)                               # idempotent
+    gpu_ctx.renderFrameInto(cam, opts, out)
+    assert np.array_equal(out, a)
+    gpu_ctx.unpinHostBuffer(out)
+    with pytest.raises(c2.C2rtError):
+        gpu_ctx.unpinHostBuffer(out)
+    # ray statistics accumulate over the chunks
+    _, _, o2 = load_config("lecture5_640x480_t5", count_rays=1)
+    gpu_ctx.renderFrame(cam, o2)
+    st = {}
+    orc.render_frame(scene.desc, cam, opts, 0, st)
+    assert gpu_ctx.rayStats() == (st["primary"], st["shadow"])
