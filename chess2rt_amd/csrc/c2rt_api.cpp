@@ -233,6 +233,10 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
     std::memcpy(p.ambient, ctx->ambient, sizeof p.ambient);
     p.max_trace_depth = ctx->max_trace_depth;
     p.cam = *cam;
+    for (int i = 0; i < 3; ++i) {
+        p.cam_du[i] = cam->up_right[i] - cam->up_left[i];
+        p.cam_dv[i] = cam->down_left[i] - cam->up_left[i];
+    }
     p.width = o->width;
     p.height = o->height;
     p.taps = o->taps;

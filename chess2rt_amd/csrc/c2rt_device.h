@@ -107,6 +107,7 @@ struct RenderParams {
     uint32_t max_trace_depth;
 
     c2rt_camera_frame cam;
+    double cam_du[3], cam_dv[3];   /* up_right - up_left, down_left - up_left (rt/camera.d:140-142) */
 
     uint32_t width, height;        /* frame */
     uint32_t taps;

@@ -215,10 +215,9 @@ DEV bool sphere_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
  * `mult < 0` is decided from the operand signs (an IEEE quotient is negative
  * iff exactly one operand is and the numerator is non-zero), which skips the
  * division for every face behind the origin. */
-template <int NEED>
+template <int NEED, int AXIS>
 DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, double cx,
-                    double oz, double dz, double cz, double halfSide, D3 o, D3 d,
-                    Hit &h, int axis, int &hit_axis, double &hit_side)
+                    double oz, double dz, double cz, double halfSide, D3 o, D3 d, Hit &h)
 {
     if (fabs(dy) < 1e-9) return false;
     bool found = false;
@@ -236,8 +235,8 @@ DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, doubl
         h.dist = mult;
         if (NEED >= kPoint) h.p = o + d * mult;
         if (NEED == kFull) {
-            hit_axis = axis;
-            hit_side = side;
+            /* Vector(0, side, 0) un-permuted: the face normal along AXIS */
+            h.n = mk(AXIS == 0 ? (double)side : 0.0, AXIS == 1 ? (double)side : 0.0, AXIS == 2 ? (double)side : 0.0);
             h.u = px - cx;
             h.v = pz - cz;
         }
@@ -253,16 +252,13 @@ DEV bool cube_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
     const D3 o = r.o, d = r.d;
     const D3 c = ld3(G->p);
     const double halfSide = G->p[3] * 0.5;
-    int axis = 1;
-    double side = 0;
     /* Y faces; X faces = project(1,0,2): (y,x,z); Z faces = project(0,2,1): (x,z,y) */
-    bool found = cube_sides<NEED>(o.y, d.y, c.y, o.x, d.x, c.x, o.z, d.z, c.z, halfSide, o, d, h, 1, axis, side);
-    found |= cube_sides<NEED>(o.x, d.x, c.x, o.y, d.y, c.y, o.z, d.z, c.z, halfSide, o, d, h, 0, axis, side);
-    found |= cube_sides<NEED>(o.z, d.z, c.z, o.x, d.x, c.x, o.y, d.y, c.y, halfSide, o, d, h, 2, axis, side);
+    bool found = cube_sides<NEED, 1>(o.y, d.y, c.y, o.x, d.x, c.x, o.z, d.z, c.z, halfSide, o, d, h);
+    found |= cube_sides<NEED, 0>(o.x, d.x, c.x, o.y, d.y, c.y, o.z, d.z, c.z, halfSide, o, d, h);
+    found |= cube_sides<NEED, 2>(o.z, d.z, c.z, o.x, d.x, c.x, o.y, d.y, c.y, halfSide, o, d, h);
     if (found) {
         if (NEED >= kPoint) h.g = gid;
         if (NEED == kFull) {
-            h.n = mk(axis == 0 ? side : 0.0, axis == 1 ? side : 0.0, axis == 2 ? side : 0.0);
             h.uv_pending = false;
             h.axis_n = true;
         }
@@ -644,11 +640,13 @@ struct Rng { uint64_t seed, pixel; uint32_t tap, sample, dim; };
 DEV double rng_next(Rng &r) { return rng_uniform(r.seed, r.pixel, r.tap, r.sample, r.dim++); }
 
 template <bool DOF>
-DEV void screen_ray(const c2rt_camera_frame &cam, double x, double y, int offset, Rng &rng, D3 &orig, D3 &dir)
+DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &rng, D3 &orig, D3 &dir)
 {
+    const c2rt_camera_frame &cam = P.cam;
     const D3 pos = ld3(cam.pos), upLeft = ld3(cam.up_left);
-    const D3 target = upLeft + (ld3(cam.up_right) - upLeft) * (x / cam.frame_width) +
-                      (ld3(cam.down_left) - upLeft) * (y / cam.frame_height);
+    /* (upRight - upLeft) and (downLeft - upLeft) are per-frame constants: the host
+     * does the same two IEEE subtractions once (c2rt_api.cpp fill_params) */
+    const D3 target = upLeft + ld3(P.cam_du) * (x / cam.frame_width) + ld3(P.cam_dv) * (y / cam.frame_height);
     orig = pos;
     dir = normalized(target - pos);
     if constexpr (DOF) {
@@ -729,7 +727,7 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
     Rng rng = {P.seed, pixel, tap, 0, 0};
     D3 o, d;
     if constexpr (!DOF) {
-        screen_ray<false>(P.cam, x, y, 0, rng, o, d);
+        screen_ray<false>(P, x, y, 0, rng, o, d);
         return raytrace<LEVELS>(P, cx, o, d, cnt, probe);
     } else {
         const bool stereo = P.cam.stereo_separation != 0;
@@ -741,13 +739,13 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
                 rng.dim = 0;
                 double jx = rng_next(rng), jy = rng_next(rng);
                 if (!stereo) {
-                    screen_ray<true>(P.cam, x + jx * 1, y + jy * 1, 0, rng, o, d);
+                    screen_ray<true>(P, x + jx * 1, y + jy * 1, 0, rng, o, d);
                     average = average + raytrace<LEVELS>(P, cx, o, d, cnt, probe);
                 } else {
-                    screen_ray<true>(P.cam, x + jx * 1, y + jy * 1, -1, rng, o, d);
+                    screen_ray<true>(P, x + jx * 1, y + jy * 1, -1, rng, o, d);
                     const F3 l = raytrace<LEVELS>(P, cx, o, d, cnt, probe);
                     jx = rng_next(rng), jy = rng_next(rng);
-                    screen_ray<true>(P.cam, x + jx * 1, y + jy * 1, +1, rng, o, d);
+                    screen_ray<true>(P, x + jx * 1, y + jy * 1, +1, rng, o, d);
                     const F3 r = raytrace<LEVELS>(P, cx, o, d, cnt, nullptr);
                     average = average + combine_stereo(l, r);
                 }
@@ -755,12 +753,12 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
             return average / (float)ns;
         }
         if (!stereo) {
-            screen_ray<true>(P.cam, x, y, 0, rng, o, d);
+            screen_ray<true>(P, x, y, 0, rng, o, d);
             return raytrace<LEVELS>(P, cx, o, d, cnt, probe);
         }
-        screen_ray<true>(P.cam, x, y, -1, rng, o, d);
+        screen_ray<true>(P, x, y, -1, rng, o, d);
         const F3 l = raytrace<LEVELS>(P, cx, o, d, cnt, probe);
-        screen_ray<true>(P.cam, x, y, +1, rng, o, d);
+        screen_ray<true>(P, x, y, +1, rng, o, d);
         const F3 r = raytrace<LEVELS>(P, cx, o, d, cnt, nullptr);
         return combine_stereo(l, r);
     }
