@@ -42,6 +42,8 @@ WORKLOADS = {
     "zaphod_4k_4spp": ("zaphod.sdl", 3840, 2160, 4, False),      # BASELINE configs[3], DOF off
     "zaphod_4k_dof25": ("zaphod.sdl", 3840, 2160, 1, True),      # zaphod.sdl as shipped: 25 DOF samples/pixel, build RNG
     "lecture5_8k_4spp": ("lecture5.sdl", 7680, 4320, 4, False),  # BASELINE configs[4] (per-frame size)
+    # BUILD-AUTHORED nested-CSG scene (depth 4): the "LDS CSG-stack stress" intent of configs[3], which zaphod.sdl cannot serve (no CSG in it)
+    "csg_stress_4k_4spp": ("csg_stress.sdl", 3840, 2160, 4, False),
 }
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
