@@ -1,0 +1,73 @@
+"""Seeded random scene generator (SDL text) for GPU-vs-oracle fuzzing."""
+import random
+
+
+def _v(r, lo, hi, n=3):
+    return " ".join("%.6g" % r.uniform(lo, hi) for _ in range(n))
+
+
+def random_scene_sdl(seed, max_depth=3):
+    r = random.Random(seed)
+    geoms, names = [], []
+
+    def prim(kind=None):
+        kind = kind or r.choice(["Sphere", "Sphere", "Cube", "Cube", "Plane"])
+        name = "g%d" % len(names)
+        if kind == "Sphere":
+            geoms.append('Sphere "%s" { center %s; R %.6g }' % (name, _v(r, -40, 40), r.uniform(5, 30)))
+        elif kind == "Cube":
+            geoms.append('Cube "%s" { center %s; side %.6g }' % (name, _v(r, -40, 40), r.uniform(8, 45)))
+        else:
+            geoms.append('Plane "%s" { y %.6g }' % (name, r.uniform(-20, 20)))
+        names.append(name)
+        return name
+
+    def csg(depth):
+        if depth == 0 or r.random() < 0.25:
+            return prim(r.choice(["Sphere", "Cube", "Cube", "Sphere", "Plane"]) if r.random() < 0.2 else r.choice(["Sphere", "Cube"]))
+        # children first (the loader resolves names at deserialize time)
+        left = csg(depth - 1) if r.random() < 0.6 else prim(r.choice(["Sphere", "Cube"]))
+        right = csg(depth - 1) if r.random() < 0.6 else prim(r.choice(["Sphere", "Cube"]))
+        if r.random() < 0.15:
+            right = left                      # Op(a, a)
+        name = "g%d" % len(names)
+        geoms.append('%s "%s" { left "%s"; right "%s" }' % (r.choice(["CsgUnion", "CsgInter", "CsgDiff", "CsgDiff"]), name, left, right))
+        names.append(name)
+        return name
+
+    roots = [prim("Plane")]
+    for _ in range(r.randint(2, 5)):
+        roots.append(csg(r.randint(0, max_depth)))
+    textures = ['Checker "chk" { color1 %s; color2 %s; size %.6g }' % (_v(r, 0, 1), _v(r, 0, 1), r.uniform(3, 30)),
+                'Procedure2 "proc" { freqU %s; freqV %s; colorU { color %s; color %s; color %s }; colorV { color %s; color %s; color %s } }'
+                % (_v(r, 0.01, 0.5), _v(r, 0.01, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5)),
+                'BitmapTexture "bmp" { file "floor.bmp"; scaling %.6g }' % r.uniform(0.005, 0.05)]
+    shaders = ['Lambert "s0" { texture "chk" }', 'Lambert "s1" { texture "proc" }', 'Lambert "s2" { texture "bmp" }',
+               'Lambert "s3" { color %s }' % _v(r, 0.1, 1),
+               'Phong "s4" { color %s; exponent %.6g; strength %.6g }' % (_v(r, 0.1, 1), r.uniform(2, 90), r.uniform(0.2, 1)),
+               'Phong "s5" { texture "bmp"; exponent %.6g }' % r.uniform(5, 40)]
+    nodes = []
+    for i, g in enumerate(roots):
+        xf = ""
+        if i > 0 and r.random() < 0.5:
+            xf += "; scale %s" % _v(r, 0.5, 2.0)
+        if i > 0 and r.random() < 0.3:
+            xf += "; rotate %s" % _v(r, 0.7, 1.4)
+        if i > 0 and r.random() < 0.6:
+            xf += "; translate %s" % _v(r, -30, 30)
+        nodes.append('Node "n%d" { geometry "%s"; shader "s%d"%s }' % (i, g, r.randint(0, 5), xf))
+    lights = ['PointLight "l%d" { pos %s; color %s; power %.6g }' % (i, _v(r, -150, 150), _v(r, 0.3, 1), r.uniform(8000, 60000))
+              for i in range(r.randint(1, 3))]
+    lights[0] = 'PointLight "l0" { pos %.6g %.6g %.6g; color 1 1 1; power 50000 }' % (r.uniform(-100, 100), r.uniform(80, 200), r.uniform(-100, 100))
+    cam = "Camera { pos %.6g %.6g %.6g; yaw %.6g; pitch %.6g; roll %.6g; fov %.6g }" % (
+        r.uniform(-30, 30), r.uniform(30, 90), r.uniform(-160, -90), r.uniform(-15, 15), r.uniform(-35, -10), r.uniform(-5, 5), r.uniform(50, 95))
+    return "\n".join([
+        "Scene {", '  Name "fuzz%d"' % seed,
+        "  GlobalSettings { frameWidth 96; frameHeight 72; AAEnabled false; ambientLightColor %s }" % _v(r, 0, 0.2),
+        "  " + cam,
+        "  Lights {\n    " + "\n    ".join(lights) + "\n  }",
+        "  Geometries {\n    " + "\n    ".join(geoms) + "\n  }",
+        "  Textures {\n    " + "\n    ".join(textures) + "\n  }",
+        "  Shaders {\n    " + "\n    ".join(shaders) + "\n  }",
+        "  Nodes {\n    " + "\n    ".join(nodes) + "\n  }",
+        "}", ""])
