@@ -45,10 +45,12 @@ __device__ __noinline__ double c2_cos(double a) { return cos(a); }
 #ifndef C2RT_OCC
 #if defined(C2RT_UNIT) && C2RT_UNIT == 0
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
-#elif defined(C2RT_UNIT) && C2RT_UNIT >= 2
-/* nested CSG: the out-of-line levels spill around every call and the LDS slabs
- * (12 KiB per level and wave) already cap residency near one wave per SIMD, so
- * take the whole register file (measured 1.9x faster than (3,3) on csg_stress) */
+#elif defined(C2RT_UNIT) && C2RT_UNIT == 2
+#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(2, 2))) /* 198 VGPRs, no scratch */
+#elif defined(C2RT_UNIT) && C2RT_UNIT >= 3
+/* every nesting level keeps its stepping state live (all levels are inlined
+ * once): ~255 VGPRs without scratch; the LDS slabs (12 KiB per level and wave)
+ * cap residency below one wave per SIMD anyway */
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
@@ -127,7 +129,13 @@ DEV void finish_uv(Hit &h)
 }
 
 /* what a caller needs back from an intersect call */
-enum Need { kBool = 0, kPoint = 1, kFull = 2 };
+enum Need {
+    kBool = 0,  /* hit / no hit (and the distance) */
+    kPoint = 1, /* + p and the leaf geometry */
+    kFull = 2,  /* + normal and u,v */
+    kRt = 3     /* kPoint, and kFull for the lanes whose run-time `full` flag is set */
+};
+#define C2RT_WANT_FULL(NEED, full) ((NEED) == kFull || ((NEED) == kRt && (full)))
 
 /* what the trace needs below the shading level: table bases (SGPRs), the
  * wave's CSG slabs and the lane.  Deliberately NOT a pointer to the kernel
@@ -155,7 +163,7 @@ struct ORay {
 
 /* Plane.intersect — rt/geometry.d:30-59 */
 template <int NEED>
-DEV bool plane_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
+DEV bool plane_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h, bool full)
 {
     const D3 o = r.o, d = r.d;
     const double y = G->p[0], limit = G->p[1];
@@ -166,13 +174,13 @@ DEV bool plane_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
     if (fabs(p.x) > limit || fabs(p.z) > limit) return false;
     h.dist = mult;
     if (NEED >= kPoint) { h.p = p; h.g = gid; }
-    if (NEED == kFull) { h.n = mk(0, 1, 0); h.u = p.x; h.v = p.z; h.uv_pending = false; h.axis_n = true; }
+    if (C2RT_WANT_FULL(NEED, full)) { h.n = mk(0, 1, 0); h.u = p.x; h.v = p.z; h.uv_pending = false; h.axis_n = true; }
     return true;
 }
 
 /* Sphere.intersect — rt/geometry.d:92-125 */
 template <int NEED>
-DEV bool sphere_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
+DEV bool sphere_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h, bool full)
 {
     const D3 o = r.o, d = r.d;
     const D3 c = ld3(G->p);
@@ -201,7 +209,7 @@ DEV bool sphere_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
         const D3 p = o + d * sol;
         h.p = p;
         h.g = gid;
-        if (NEED == kFull) {
+        if (C2RT_WANT_FULL(NEED, full)) {
             h.n = normalized(p - c);
             h.u = p.x - c.x;
             h.v = p.z - c.z;
@@ -222,7 +230,7 @@ DEV bool sphere_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
  * division for every face behind the origin. */
 template <int NEED, int AXIS>
 DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, double cx,
-                    double oz, double dz, double cz, double halfSide, D3 o, D3 d, Hit &h)
+                    double oz, double dz, double cz, double halfSide, D3 o, D3 d, Hit &h, bool full)
 {
     if (fabs(dy) < 1e-9) return false;
     bool found = false;
@@ -239,7 +247,7 @@ DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, doubl
         if (px < cx - halfSide || px > cx + halfSide || pz < cz - halfSide || pz > cz + halfSide) continue;
         h.dist = mult;
         if (NEED >= kPoint) h.p = o + d * mult;
-        if (NEED == kFull) {
+        if (C2RT_WANT_FULL(NEED, full)) {
             /* Vector(0, side, 0) un-permuted: the face normal along AXIS */
             h.n = mk(AXIS == 0 ? (double)side : 0.0, AXIS == 1 ? (double)side : 0.0, AXIS == 2 ? (double)side : 0.0);
             h.u = px - cx;
@@ -252,18 +260,18 @@ DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, doubl
 
 /* Cube.intersect — rt/geometry.d:172-196 */
 template <int NEED>
-DEV bool cube_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h)
+DEV bool cube_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h, bool full)
 {
     const D3 o = r.o, d = r.d;
     const D3 c = ld3(G->p);
     const double halfSide = G->p[3] * 0.5;
     /* Y faces; X faces = project(1,0,2): (y,x,z); Z faces = project(0,2,1): (x,z,y) */
-    bool found = cube_sides<NEED, 1>(o.y, d.y, c.y, o.x, d.x, c.x, o.z, d.z, c.z, halfSide, o, d, h);
-    found |= cube_sides<NEED, 0>(o.x, d.x, c.x, o.y, d.y, c.y, o.z, d.z, c.z, halfSide, o, d, h);
-    found |= cube_sides<NEED, 2>(o.z, d.z, c.z, o.x, d.x, c.x, o.y, d.y, c.y, halfSide, o, d, h);
+    bool found = cube_sides<NEED, 1>(o.y, d.y, c.y, o.x, d.x, c.x, o.z, d.z, c.z, halfSide, o, d, h, full);
+    found |= cube_sides<NEED, 0>(o.x, d.x, c.x, o.y, d.y, c.y, o.z, d.z, c.z, halfSide, o, d, h, full);
+    found |= cube_sides<NEED, 2>(o.z, d.z, c.z, o.x, d.x, c.x, o.y, d.y, c.y, halfSide, o, d, h, full);
     if (found) {
         if (NEED >= kPoint) h.g = gid;
-        if (NEED == kFull) {
+        if (C2RT_WANT_FULL(NEED, full)) {
             h.uv_pending = false;
             h.axis_n = true;
         }
@@ -313,7 +321,7 @@ DEV bool geom_is_inside(const Ctx &cx, int gid, D3 p)
 /* ------------------------------------------------------------------ */
 
 template <int LEVEL, int NEED>
-__device__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h);
+__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h, bool full);
 
 /* CsgOp.intersect (+ CsgDiff.intersect) for a CSG whose subtree has at most
  * LEVEL nesting levels.  The hit lists of findAllIntersections
@@ -322,11 +330,109 @@ __device__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h);
  * and shell-sorted exactly as util/array.d:95-111 does (same tie behaviour),
  * walked with the in/out toggles of rt/geometry.d:303-329 (including the
  * `current.g is left` leaf-identity test), and the winning hit is then
- * re-derived by replaying its child's stepping up to k. */
+ * re-derived by replaying its child's stepping up to k.
+ *
+ * The four child-stepping loops (collect left, collect right, replay left,
+ * replay right) run as ONE wave-uniform loop with a SINGLE call site for the
+ * level below, so every nesting level is inlined exactly once: code size is
+ * linear in the depth, there are no out-of-line calls and no scratch, and the
+ * child's geometry record stays a scalar load.  Whether the replayed hit needs
+ * its normal / u,v is a per-lane flag (`full`), because lanes replay at
+ * different steps. */
 template <int LEVEL, int NEED>
-__device__ bool csg_intersect(const Ctx &cx, const DevGeom *G, const ORay &ray, Hit &h)
+__device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, const ORay &ray, Hit &h, bool full)
 {
     static_assert(LEVEL >= 1, "CSG needs a slab");
+    double *ldist = reinterpret_cast<double *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel) + cx.lane;
+    uint32_t *ltag = reinterpret_cast<uint32_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
+    const int type = G->type, left = G->left, right = G->right, flags = G->flags;
+    const D3 d = ray.d;
+    const bool want_full = NEED == kFull || (NEED == kRt && full);
+
+    int nL = 0, n = 0;
+    int wside = -1, wk = 0; /* the winning entry: which child, which of its hits */
+    Hit t;
+    t.dist = 1e99;
+    constexpr int kPasses = NEED == kBool ? 2 : 4; /* 0/1: collect left/right, 2/3: replay left/right */
+#pragma unroll 1
+    for (int pass = 0; pass < kPasses; ++pass) {
+        const int side = pass & 1;
+        const int child = side ? right : left; /* wave-uniform */
+        const bool replay = pass >= 2;
+        if (replay && wside != side) continue; /* this lane's winner came from the other child */
+        const int limit = replay ? wk + 1 : kMaxCsgHits;
+        ORay rr = ray;
+        double cur = 0;
+        int k = 0;
+        while (k < limit) {
+            t.dist = 1e99;
+            if (!geom_intersect<LEVEL - 1, kRt>(cx, child, rr, t, replay && k == wk && want_full)) break;
+            t.dist += cur;
+            cur = t.dist;
+            rr.o = t.p + d * 1e-6;
+            if (!replay) {
+                ldist[(n + k) * kWave] = t.dist;
+                ltag[(n + k) * kWave] = ((uint32_t)t.g << 8) | ((uint32_t)side << 4) | (uint32_t)k;
+            }
+            ++k;
+        }
+        if (replay) break; /* `t` is the re-derived winner (data = current, rt/geometry.d:326) */
+        if (side == 0) nL = k;
+        n += k;
+        /* exact shortcuts (GeomFlags): nothing can switch the operator on */
+        if (side == 0 && k == 0 && (flags & kCsgShortA)) return false;
+        if (side == 1 && k == 0 && (flags & kCsgShortB)) return false;
+        if (side == 0) continue;
+
+        /* both lists are in: sort — util/array.d:95-111 (index rewound by the inner while) */
+        for (int inc = n / 2; inc;) {
+            for (int i = 0; i < n; ++i) {
+                const double ed = ldist[i * kWave];
+                const uint32_t et = ltag[i * kWave];
+                while (i >= inc && ldist[(i - inc) * kWave] > ed) {
+                    ldist[i * kWave] = ldist[(i - inc) * kWave];
+                    ltag[i * kWave] = ltag[(i - inc) * kWave];
+                    i -= inc;
+                }
+                ldist[i * kWave] = ed;
+                ltag[i * kWave] = et;
+            }
+            inc = (inc == 2) ? 1 : (int)(inc * 5.0 / 11);
+        }
+        bool inL = (nL & 1) != 0, inR = ((n - nL) & 1) != 0;
+        int win = -1;
+        for (int i = 0; i < n; ++i) {
+            const uint32_t tag = ltag[i * kWave];
+            if ((int)(tag >> 8) == left) inL = !inL; else inR = !inR;
+            const bool in = type == C2RT_GEOM_CSG_UNION ? (inL || inR)
+                          : (type == C2RT_GEOM_CSG_INTER ? (inL && inR) : (inL && !inR));
+            if (in) { win = i; break; }
+        }
+        if (win < 0) return false;
+        const double wdist = ldist[win * kWave];
+        if (wdist > h.dist) return false;
+        if (NEED == kBool) { h.dist = wdist; return true; }
+        const uint32_t wtag = ltag[win * kWave];
+        wside = (wtag >> 4) & 1;
+        wk = wtag & 15;
+    }
+    h = t;
+
+    if (want_full && type == C2RT_GEOM_CSG_DIFF) { /* CsgDiff.intersect — rt/geometry.d:382-397 */
+        if (geom_is_inside<LEVEL - 1>(cx, right, h.p - d * 1e-6) != geom_is_inside<LEVEL - 1>(cx, right, h.p + d * 1e-6))
+            h.n = -h.n;
+    }
+    return true;
+}
+
+/* The same for a CSG whose children are both primitives (the innermost level, by
+ * far the most executed one): the three stepping loops are written out, with
+ * compile-time NEED for the collect loops — measurably faster than the single
+ * call-site form, and the duplicated primitive code is small. */
+template <int NEED>
+__device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom *G, const ORay &ray, Hit &h, bool full)
+{
+    constexpr int LEVEL = 1;
     double *ldist = reinterpret_cast<double *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel) + cx.lane;
     uint32_t *ltag = reinterpret_cast<uint32_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
     const int type = G->type, left = G->left, right = G->right, flags = G->flags;
@@ -343,7 +449,7 @@ __device__ bool csg_intersect(const Ctx &cx, const DevGeom *G, const ORay &ray, 
         while (k < kMaxCsgHits) {
             Hit t;
             t.dist = 1e99;
-            if (!geom_intersect<LEVEL - 1, kPoint>(cx, child, rr, t)) break;
+            if (!geom_intersect<0, kPoint>(cx, child, rr, t, false)) break;
             t.dist += cur;
             cur = t.dist;
             rr.o = t.p + d * 1e-6;
@@ -397,52 +503,45 @@ __device__ bool csg_intersect(const Ctx &cx, const DevGeom *G, const ORay &ray, 
     for (int i = 0; i < wk; ++i) {
         Hit t;
         t.dist = 1e99;
-        geom_intersect<LEVEL - 1, kPoint>(cx, child, rr, t);
+        geom_intersect<0, kPoint>(cx, child, rr, t, false);
         t.dist += cur;
         cur = t.dist;
         rr.o = t.p + d * 1e-6;
     }
     Hit t;
     t.dist = 1e99;
-    geom_intersect<LEVEL - 1, NEED>(cx, child, rr, t);
+    geom_intersect<0, NEED>(cx, child, rr, t, full);
     t.dist += cur;
     h = t;
 
-    if (NEED == kFull && type == C2RT_GEOM_CSG_DIFF) { /* CsgDiff.intersect — rt/geometry.d:382-397 */
+    if (C2RT_WANT_FULL(NEED, full) && type == C2RT_GEOM_CSG_DIFF) { /* CsgDiff.intersect — rt/geometry.d:382-397 */
         if (geom_is_inside<LEVEL - 1>(cx, right, h.p - d * 1e-6) != geom_is_inside<LEVEL - 1>(cx, right, h.p + d * 1e-6))
             h.n = -h.n;
     }
     return true;
 }
 
-/* levels >= 2 are real calls so that code size stays linear in the depth */
+/* Geometry.intersect on a given record: `G` is wave-uniform, so this is a scalar branch. */
 template <int LEVEL, int NEED>
-__device__ __noinline__ bool csg_intersect_call(const Ctx &cx, const DevGeom *G, const ORay &r, Hit &h)
-{
-    return csg_intersect<LEVEL, NEED>(cx, G, r, h);
-}
-
-/* Geometry.intersect: `gid` is wave-uniform, so this is a scalar branch. */
-template <int LEVEL, int NEED>
-__device__ __forceinline__ bool geom_intersect_rec(const Ctx &cx, const DevGeom *G, int gid, const ORay &r, Hit &h)
+__device__ __forceinline__ bool geom_intersect_rec(const Ctx &cx, const DevGeom *G, int gid, const ORay &r, Hit &h, bool full)
 {
     const int type = G->type;
-    if (type == C2RT_GEOM_PLANE) return plane_intersect<NEED>(G, gid, r, h);
-    if (type == C2RT_GEOM_SPHERE) return sphere_intersect<NEED>(G, gid, r, h);
-    if (type == C2RT_GEOM_CUBE) return cube_intersect<NEED>(G, gid, r, h);
+    if (type == C2RT_GEOM_PLANE) return plane_intersect<NEED>(G, gid, r, h, full);
+    if (type == C2RT_GEOM_SPHERE) return sphere_intersect<NEED>(G, gid, r, h, full);
+    if (type == C2RT_GEOM_CUBE) return cube_intersect<NEED>(G, gid, r, h, full);
     if constexpr (LEVEL >= 2) {
-        return csg_intersect_call<LEVEL, NEED>(cx, G, r, h);
+        return csg_intersect<LEVEL, NEED>(cx, G, r, h, full);
     } else if constexpr (LEVEL == 1) {
-        return csg_intersect<1, NEED>(cx, G, r, h);
+        return csg_intersect_leaf<NEED>(cx, G, r, h, full);
     } else {
         return false;
     }
 }
 
 template <int LEVEL, int NEED>
-__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h)
+__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h, bool full)
 {
-    return geom_intersect_rec<LEVEL, NEED>(cx, cx.geoms + gid, gid, r, h);
+    return geom_intersect_rec<LEVEL, NEED>(cx, cx.geoms + gid, gid, r, h, full);
 }
 
 /* ------------------------------------------------------------------ */
@@ -497,7 +596,7 @@ DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &b
     if (G->type >= C2RT_GEOM_CUBE && (G->flags & kGeomBounded) && misses_bound(G, rc)) return false;
     Hit h;
     h.dist = best.dist * len;
-    if (!geom_intersect_rec<LEVELS, NEED>(cx, G, gid, rc, h)) return false;
+    if (!geom_intersect_rec<LEVELS, NEED>(cx, G, gid, rc, h, false)) return false;
     if (NEED == kBool) return true;
     best.dist = h.dist / len;
     best.g = h.g;
