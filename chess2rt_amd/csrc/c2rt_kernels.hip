@@ -139,7 +139,7 @@ enum Need {
 
 /* what the trace needs below the shading level: table bases (SGPRs), the
  * wave's CSG slabs and the lane.  Deliberately NOT a pointer to the kernel
- * arguments, so that out-of-line CSG levels do not force them into scratch. */
+ * arguments (which would have to be materialised in scratch if it escaped). */
 struct Ctx {
     const DevGeom *geoms;
     const DevNode *nodes;
