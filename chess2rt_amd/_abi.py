@@ -98,7 +98,7 @@ class RenderOpts(C.Structure):
         ("strip_world", C.c_uint32),
         ("seed", C.c_uint64),
         ("count_rays", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("prepass_bucket", C.c_uint32),
     ]
 
 

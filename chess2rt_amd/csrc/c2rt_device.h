@@ -111,6 +111,7 @@ struct RenderParams {
 
     uint32_t width, height;        /* frame */
     uint32_t taps;
+    uint32_t prepass_bucket;       /* > 0: prepassOnly preview with this bucket size */
     uint32_t strip_height, strip_rank, strip_world;
     uint32_t local_rows;           /* rows this launch renders */
     uint32_t row_offset;           /* first local row of this launch (chunked host-output renders) */

@@ -919,7 +919,16 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     cx.lds = lds;
     cx.lane = lane;
     Counters cnt = {0, 0};
-    const uint64_t pixel = (uint64_t)y * P.width + x;
+    /* prepassOnly (rt/renderer.d:110-130): the pixel shows the sample of the
+     * top-left pixel of its 16x16 block inside its bucket */
+    uint32_t sx = x, sy = y;
+    if (P.prepass_bucket) {
+        const uint32_t bs = P.prepass_bucket;
+        const uint32_t bx = x / bs * bs, by = y / bs * bs;
+        sx = bx + ((x - bx) & ~15u);
+        sy = by + ((y - by) & ~15u);
+    }
+    const uint64_t pixel = (uint64_t)sy * P.width + sx;
     const uint32_t ntaps = P.taps;
 
     /* renderPixelNoAA — rt/renderer.d:223-228; renderPixelAA — :233-251.
@@ -928,7 +937,7 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     F3 accum = mkf(0, 0, 0);
 #pragma unroll 1
     for (uint32_t s = 0; s < ntaps; ++s) {
-        const F3 c = render_sample<LEVELS, DOF>(P, cx, (double)x + k_aa_x[s], (double)y + k_aa_y[s], pixel, s, cnt, nullptr);
+        const F3 c = render_sample<LEVELS, DOF>(P, cx, (double)sx + k_aa_x[s], (double)sy + k_aa_y[s], pixel, s, cnt, nullptr);
         accum = s == 0 ? c : accum + c;
     }
     if (ntaps > 1) accum = accum / (float)ntaps; /* `accum / 5`: Color / float */

@@ -59,13 +59,14 @@ struct Renderer {
     int renderRT(const c2rt_camera_frame &cam)
     {
         int st = ensureUploaded();
-        if (st == C2RT_OK) {
-            // prepass (rt/renderer.d:110-127) only paints a preview that pass 2
-            // overwrites; prepassOnly leaves the frame to the caller's CPU path.
-            if (hs->scene->settings.prepassOnly) st = C2RT_ERR_UNSUPPORTED;
-        }
-        if (st == C2RT_OK) {
-            const c2rt_render_opts o = opts_of(*hs->scene);
+        const GlobalSettings &gs = hs->scene->settings;
+        if (st == C2RT_OK && gs.prepassOnly && !gs.prepassEnabled) {
+            // rt/renderer.d:110,129: no prepass and an immediate return — the frame is left untouched
+        } else if (st == C2RT_OK) {
+            // the prepass (rt/renderer.d:110-127) only paints a preview that pass 2
+            // overwrites, unless prepassOnly stops there
+            c2rt_render_opts o = opts_of(*hs->scene);
+            if (gs.prepassOnly) o.prepass_bucket = gs.bucketSize;
             st = c2rt_render_frame(ctx, &cam, &o, outputImage, isStopRequested);
         }
         if (isRendering) *isRendering = 0; // end(): atomicStore(*isRendering, false) — rt/renderer.d:87-91

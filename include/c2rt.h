@@ -188,7 +188,11 @@ typedef struct c2rt_render_opts {
     uint32_t strip_world;
     uint64_t seed;                 /* counter-based RNG seed (DOF only) */
     uint32_t count_rays;           /* 1: also count primary/shadow rays cast */
-    uint32_t reserved;
+    /* 0: the normal frame.  N > 0: `prepassOnly` (rt/renderer.d:110-130) with
+     * bucketSize N: every 16x16 block of every NxN bucket is filled with the one
+     * sample taken at its top-left pixel; taps are ignored (the reference
+     * returns before the AA pass). */
+    uint32_t prepass_bucket;
 } c2rt_render_opts;
 
 /* What `renderPixel` returns (TraceResult, rt/renderer.d:15-21). */

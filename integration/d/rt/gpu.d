@@ -61,7 +61,7 @@ extern (C) nothrow @nogc
     {
         uint width, height, taps, strip_height, strip_rank, strip_world;
         ulong seed;
-        uint count_rays, reserved;
+        uint count_rays, prepass_bucket;
     }
 
     struct c2rt_trace_result

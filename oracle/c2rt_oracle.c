@@ -886,14 +886,6 @@ static uint32_t local_row(const c2rt_render_opts *o, uint32_t y)
     uint32_t sh = strip_h_(o);
     return (y / sh / o->strip_world) * sh + y % sh;
 }
-static uint32_t local_rows(const c2rt_render_opts *o)
-{
-    if (o->strip_world <= 1) return o->height;
-    uint32_t n = 0;
-    for (uint32_t y = 0; y < o->height; ++y) n += (uint32_t)row_is_local(o, y);
-    return n;
-}
-
 typedef struct { int x0, y0, x1, y1; } Box;
 
 typedef struct {
@@ -978,6 +970,7 @@ static int check_args(Scene *s, const c2rt_camera_frame *cam, const c2rt_render_
     if (o->width == 0 || o->height == 0) return C2RT_ERR_INVALID_ARG;
     if (o->taps != C2RT_TAPS_1 && o->taps != C2RT_TAPS_REF5 && o->taps != C2RT_TAPS_4) return C2RT_ERR_INVALID_ARG;
     if (o->strip_world > 1 && o->strip_rank >= o->strip_world) return C2RT_ERR_INVALID_ARG;
+    if (o->prepass_bucket && (cam->dof || o->prepass_bucket > 65536)) return C2RT_ERR_UNSUPPORTED;
     return C2RT_OK;
 }
 
@@ -1002,6 +995,32 @@ int orc_render_frame(const c2rt_scene_desc *scene, const c2rt_camera_frame *cam,
     job.buckets = bucket_list((int)opts->width, (int)opts->height, &job.n_buckets);
     atomic_init(&job.primary, 0);
     atomic_init(&job.shadow, 0);
+    if (opts->prepass_bucket) {
+        /* pass 1 with prepassOnly — rt/renderer.d:110-130: one sample per 16x16
+         * block of every bucket, drawRect over the block (serial in the reference) */
+        free(job.buckets);
+        const int BS = (int)opts->prepass_bucket, W = (int)opts->width, H = (int)opts->height;
+        Counters cnt = {0, 0};
+        for (int by = 0; by < H; by += BS)
+            for (int bx = 0; bx < W; bx += BS) {
+                const int bw = (bx + BS < W ? BS : W - bx), bh = (by + BS < H ? BS : H - by);
+                for (int dy = 0; dy < bh; dy += 16) {
+                    const int ey = dy + 16 < bh ? dy + 16 : bh;
+                    for (int dx = 0; dx < bw; dx += 16) {
+                        const int ex = dx + 16 < bw ? dx + 16 : bw;
+                        const int x0 = bx + dx, y0 = by + dy;
+                        Col c = render_sample(&job.rc, x0, y0, (uint64_t)y0 * W + (uint64_t)x0, 0, &cnt, NULL);
+                        for (int y = y0; y < by + ey; ++y) {
+                            if (!row_is_local(opts, (uint32_t)y)) continue;
+                            float *row = out_rgb + 3 * (size_t)local_row(opts, (uint32_t)y) * W;
+                            for (int x = x0; x < bx + ex; ++x) row[3 * x] = c.r, row[3 * x + 1] = c.g, row[3 * x + 2] = c.b;
+                        }
+                    }
+                }
+            }
+        if (stats) { stats->primary_rays = cnt.primary; stats->shadow_rays = cnt.shadow; }
+        return C2RT_OK;
+    }
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
     int passes = opts->taps == C2RT_TAPS_1 ? 1 : 2;
     for (int p = 0; p < passes; ++p) {

@@ -395,3 +395,31 @@ def test_random_scene_fuzz(gpu_ctx, tmp_path, scenes_dir):
             assert md <= TOL and nbad == 0, (seed, md)
             assert (pr, sh) == (st["primary"], st["shadow"]), seed
     print("fuzz: worst max|d| over 120 scenes = %.3g" % worst)
+
+
+def test_prepass_only_preview(gpu_ctx, tmp_path):
+    scene, cam, _ = load_config("lecture5_333x217_t4")
+    gpu_ctx.uploadScene(scene.desc)
+    for bucket in (48, 40):
+        _, _, po = load_config("lecture5_333x217_t4", prepass_bucket=bucket)
+        a = gpu_ctx.renderFrame(cam, po)
+        ref = orc.render_frame(scene.desc, cam, po, 0)
+        assert maxdiff(a, ref)[0] <= TOL
+    # through the host mirror: GlobalSettings.prepassOnly
+    text = open(os.path.join(SCENES, "lecture4.sdl")).read().replace("frameHeight\t\t\t480", "frameHeight 480\n        prepassOnly true")
+    assert "prepassOnly" in text
+    s = _load_text(tmp_path, text, "pre.sdl")
+    assert s.settings.prepass_only == 1 and s.settings.prepass_enabled == 1
+    img = c2.Renderer(s, gpu_ctx).renderRT()
+    cam4 = s.beginFrame()
+    ref = orc.render_frame(s.desc, cam4, s.renderOpts(prepass_bucket=48), 0)
+    assert maxdiff(img, ref)[0] <= TOL
+    assert np.array_equal(img[0:16, 16:32], np.broadcast_to(img[0, 16], (16, 16, 3)))   # blocky
+    # prepassOnly without prepassEnabled: the reference returns at once, frame untouched
+    s2 = _load_text(tmp_path, text.replace("prepassOnly true", "prepassOnly true\n        prepassEnabled false"), "pre2.sdl")
+    out = np.full((480, 640, 3), 7.0, np.float32)
+    flag = np.ones(1, np.uint8)
+    r = c2.Renderer(s2, gpu_ctx)
+    r.renderSceneAsync(out, flag)
+    r.wait()
+    assert flag[0] == 0 and (out == 7.0).all()

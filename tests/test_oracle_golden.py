@@ -295,3 +295,16 @@ def _close(a, b):
             return a is b
         return a == b or abs(a - b) <= 1e-12 * max(1.0, abs(a), abs(b))
     return a == b
+
+
+def test_prepass_only_is_block_replication_of_single_samples():
+    """prepassOnly (rt/renderer.d:110-130): every 16x16 block of every bucket shows its top-left sample."""
+    scene, cam, opts = load_config("lecture5_333x217_t4")
+    full = orc.render_frame(scene.desc, cam, scene.renderOpts(taps=1), 0)
+    for bucket in (48, 40):
+        _, _, po = load_config("lecture5_333x217_t4", prepass_bucket=bucket)
+        pre = orc.render_frame(scene.desc, cam, po, 0)
+        ys, xs = np.mgrid[0:opts.height, 0:opts.width]
+        bx, by = xs // bucket * bucket, ys // bucket * bucket
+        sx, sy = bx + (xs - bx) // 16 * 16, by + (ys - by) // 16 * 16
+        assert np.array_equal(pre, full[sy, sx])
