@@ -19,7 +19,10 @@ namespace c2rt {
 
 constexpr int kMaxCsgHits = C2RT_MAX_CSG_HITS; /* per CSG child per ray */
 constexpr int kCsgEntries = 2 * kMaxCsgHits;
-constexpr int kTileW = 8, kTileH = 8;          /* one wavefront = one 8x8 pixel tile */
+#ifndef C2RT_TILE_W
+#define C2RT_TILE_W 8
+#endif
+constexpr int kTileW = C2RT_TILE_W, kTileH = 64 / C2RT_TILE_W; /* one wavefront = one 8x8 pixel tile */
 constexpr int kWave = 64;
 #ifndef C2RT_WAVES_PER_BLOCK
 #define C2RT_WAVES_PER_BLOCK 1

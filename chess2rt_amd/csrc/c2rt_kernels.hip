@@ -900,8 +900,8 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     if (trow >= P.tiles_y) return;
     const uint32_t tcol = bcol * kWavesPerBlock + wave;
 
-    const uint32_t x = tcol * kTileW + (lane & 7);
-    const uint32_t lr0 = trow * kTileH + (lane >> 3); /* row within this launch */
+    const uint32_t x = tcol * kTileW + (lane % kTileW);
+    const uint32_t lr0 = trow * kTileH + (lane / kTileW); /* row within this launch */
     if (x >= P.width || lr0 >= P.local_rows) return;
     const uint32_t lr = lr0 + P.row_offset;          /* local row */
 
