@@ -463,7 +463,11 @@ static int csg_bool_op(int type, int inL, int inR)
 static void csg_find_all(Scene *s, int32_t geom, Ray ray, IDArray *l)
 {
     double currentLength = 0;
-    for (;;) {
+    /* The reference loops `while (true)` and never terminates when the 1e-6
+     * step is absorbed (huge coordinates) or the hit is NaN; the build caps
+     * the list at C2RT_MAX_CSG_HITS per child (include/c2rt.h), on the device
+     * and here alike.  A sane primitive yields at most 2 hits. */
+    for (size_t steps = 0; steps < C2RT_MAX_CSG_HITS; ++steps) {
         ID temp = id_init();
         temp.dist = 1e99;
         if (!geom_intersect(s, geom, ray, &temp)) break;

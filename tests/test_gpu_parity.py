@@ -423,3 +423,40 @@ def test_prepass_only_preview(gpu_ctx, tmp_path):
     r.renderSceneAsync(out, flag)
     r.wait()
     assert flag[0] == 0 and (out == 7.0).all()
+
+
+def test_pathological_scenes_terminate_and_match(gpu_ctx, tmp_path):
+    """Inputs on which the reference itself never terminates (findAllIntersections loops for ever when
+    `p + dir*1e-6 == p` or the hit is NaN) or degenerates (NaN camera, zero-size primitives): the device
+    path and the oracle both cap the hit lists at C2RT_MAX_CSG_HITS, must terminate and must agree."""
+    cases = {
+        # stepping by 1e-6 is absorbed at 1e12: the reference would never leave the first hit
+        "absorbed_eps": ('''Scene { Camera { pos 0 0 -3e12; fov 40 }
+            Lights { PointLight "k" { pos 0 4e12 -4e12; color 1 1 1; power 1e27 } }
+            Geometries { Cube "c" { center 0 0 0; side 1e12 }; Sphere "s" { center 0 0 0; R 6e11 }; CsgDiff "d" { left "c"; right "s" } }
+            Shaders { Lambert "l" { } }
+            Nodes { Node "n" { geometry "d"; shader "l" } } }''', True),
+        "nan_camera": ('''Scene { Camera { fov 60 }
+            Lights { PointLight "k" { pos 0 10 0; color 1 1 1; power 100 } }
+            Geometries { Sphere "s" { center 0 0 5; R 1 }; Cube "c" { center 0 0 5; side 1 }; CsgUnion "u" { left "s"; right "c" } }
+            Shaders { Phong "l" { } }
+            Nodes { Node "n" { geometry "u"; shader "l" } } }''', True),
+        "degenerate_prims": ('''Scene { Camera { pos 0 1 -5; fov 60 }
+            Lights { PointLight "k" { pos 0 10 0; color 1 1 1; power 100 } }
+            Geometries { Sphere "s" { center 0 1 0; R 0 }; Cube "c" { center 0 1 0; side 0 }; CsgInter "i" { left "s"; right "c" }; Plane "p" { y 0 } }
+            Shaders { Lambert "l" { } }
+            Nodes { Node "a" { geometry "i"; shader "l" }; Node "b" { geometry "s"; shader "l"; scale 0 0 0 }; Node "f" { geometry "p"; shader "l" } } }''', True),
+    }
+    for name, (text, compare) in cases.items():
+        scene = _load_text(tmp_path, text, name + ".sdl")
+        scene.setFrameSize(64, 48)
+        scene.setAA(False)
+        cam = scene.beginFrame()
+        opts = scene.renderOpts()
+        gpu_ctx.uploadScene(scene.desc)
+        a = gpu_ctx.renderFrame(cam, opts)          # must return (bounded loops)
+        assert a.shape == (48, 64, 3)
+        if compare:
+            ref = orc.render_frame(scene.desc, cam, opts, 1)
+            assert np.array_equal(np.isnan(a), np.isnan(ref)), name
+            assert maxdiff(a, ref)[0] <= TOL, name
