@@ -93,9 +93,12 @@ class FramePipe:
     the render of frame i+1 (separate streams)."""
 
     def __init__(self, torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, strip_height, dev, overlap,
-                 backend="nccl"):
+                 backend="nccl", gather_format="float"):
         self.torch, self.dist, self.ctx, self.cam = torch, dist, ctx, cam
         self.backend = backend
+        # "float": gather the Image!Color frame (12 B/pixel, the reference's contract).
+        # "rgb32": each rank display-encodes its strips (Color.toRGB32) and 4 B/pixel cross xGMI.
+        self.rgb32 = gather_format == "rgb32" and world > 1
         self.world, self.rank, self.width, self.height = world, rank, width, height
         self.plan = c2.plan_strips(height, world, strip_height)
         self.opts = scene.renderOpts(taps=taps, strip_height=self.plan.strip_height, strip_rank=rank, strip_world=world)
@@ -104,16 +107,19 @@ class FramePipe:
         self.overlap = overlap and world > 1
         nbuf = 2 if self.overlap else 1
         self.local = [torch.zeros((self.plan.rows_pad, width, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        # what crosses the links: the float strips themselves, or their packed RGB32 encoding
+        self.wire = self.local if not self.rgb32 else [torch.zeros((self.plan.rows_pad, width), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+        wshape, wdtype = tuple(self.wire[0].shape), self.wire[0].dtype
         self.gathered = self.frame = None
         if world > 1 and rank == 0:
-            self.gathered = [torch.empty((world, self.plan.rows_pad, width, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-            self.frame = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
+            self.gathered = [torch.empty((world,) + wshape, dtype=wdtype, device=dev) for _ in range(nbuf)]
+            self.frame = torch.empty((height,) + wshape[1:], dtype=wdtype, device=dev)
         self.side = torch.cuda.Stream(dev) if self.overlap else None
         self.cpu_stage = self.cpu_list = None
         if backend == "gloo" and world > 1:   # rehearsal only: gloo gathers host tensors
-            self.cpu_stage = [torch.empty((self.plan.rows_pad, width, 3), dtype=torch.float32) for _ in range(nbuf)]
+            self.cpu_stage = [torch.empty(wshape, dtype=wdtype) for _ in range(nbuf)]
             if rank == 0:
-                self.cpu_list = [[torch.empty((self.plan.rows_pad, width, 3), dtype=torch.float32) for _ in range(world)] for _ in range(nbuf)]
+                self.cpu_list = [[torch.empty(wshape, dtype=wdtype) for _ in range(world)] for _ in range(nbuf)]
         self.work = [None] * nbuf       # outstanding gather per buffer
         self.post = [None] * nbuf       # event: rank 0 finished reading gathered[b]
         self.i = 0
@@ -124,15 +130,17 @@ class FramePipe:
         self.ctx.renderFrameDevice(self.cam, self.opts, self.local[b].data_ptr(), self.stream.cuda_stream)
         if events:
             events[1].record(self.stream)
+        if self.rgb32:
+            self.ctx.encodeRGB32(self.local[b].data_ptr(), self.wire[b].data_ptr(), self.plan.rows_pad * self.width, self.stream.cuda_stream)
 
     def _gather(self, b, async_op):
         """One gather of local[b] to rank 0 (RCCL over xGMI; `gloo` = host-staged rehearsal)."""
         dist = self.dist
         if self.backend == "gloo":
             self.stream.synchronize()
-            self.cpu_stage[b].copy_(self.local[b])
+            self.cpu_stage[b].copy_(self.wire[b])
             return dist.gather(self.cpu_stage[b], self.cpu_list[b] if self.rank == 0 else None, dst=0, async_op=async_op)
-        return dist.gather(self.local[b], list(self.gathered[b].unbind(0)) if self.rank == 0 else None, dst=0, async_op=async_op)
+        return dist.gather(self.wire[b], list(self.gathered[b].unbind(0)) if self.rank == 0 else None, dst=0, async_op=async_op)
 
     def _landed(self, b):
         if self.backend == "gloo" and self.rank == 0:
@@ -140,8 +148,9 @@ class FramePipe:
                 self.gathered[b][r].copy_(self.cpu_list[b][r])
 
     def _deinterleave(self, b, stream):
-        self.ctx.deinterleaveStrips(self.gathered[b].data_ptr(), self.frame.data_ptr(), self.width, self.height,
-                                    self.plan.strip_height, self.world, stream.cuda_stream)
+        fn = self.ctx.deinterleaveStripsRGB32 if self.rgb32 else self.ctx.deinterleaveStrips
+        fn(self.gathered[b].data_ptr(), self.frame.data_ptr(), self.width, self.height, self.plan.strip_height, self.world,
+           stream.cuda_stream)
 
     def step(self, events=None):
         torch, dist = self.torch, self.dist
@@ -229,6 +238,8 @@ def main():
     ap.add_argument("--strip-height", type=int, default=8)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = single-GPU rehearsal of the N>1 flow: host-staged gather, every rank on device 0")
+    ap.add_argument("--gather", default="float", choices=["float", "rgb32"],
+                    help="N>1: what crosses xGMI — the float Image!Color strips (default) or their RGB32 display encoding (4 B/pixel)")
     ap.add_argument("--check", action="store_true", help="N>1: compare the gathered frame with a single-rank render (bit-exact)")
     args = ap.parse_args()
 
@@ -266,7 +277,7 @@ def main():
         cam = scene.beginFrame()
         ctx.uploadScene(scene.desc)
         pipe = FramePipe(torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, args.strip_height, dev,
-                         not args.no_overlap, args.backend)
+                         not args.no_overlap, args.backend, args.gather)
         primary, shadow = count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev)
         elapsed, kernel_ms = measure(torch, dist, pipe, steps, warmup, world, dev)
         return dict(scene=scene, cam=cam, pipe=pipe, scene_file=scene_file, width=width, height=height, taps=taps,
@@ -280,6 +291,11 @@ def main():
         whole = torch.empty((r["height"], r["width"], 3), dtype=torch.float32, device=dev)
         ctx.renderFrameDevice(r["cam"], r["scene"].renderOpts(taps=r["taps"]), whole.data_ptr(), pipe.stream.cuda_stream)
         torch.cuda.synchronize(dev)
+        if pipe.rgb32:
+            packed = torch.empty((r["height"], r["width"]), dtype=torch.int32, device=dev)
+            ctx.encodeRGB32(whole.data_ptr(), packed.data_ptr(), r["height"] * r["width"], pipe.stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            whole = packed
         if not torch.equal(whole, pipe.frame):
             raise SystemExit("bench.py --check: gathered frame differs from the single-rank frame")
         print("bench.py --check: gathered frame == single-rank frame (bit-exact)", file=sys.stderr)
@@ -335,8 +351,9 @@ def main():
                 "workload": "%s %dx%d, %d tap(s)/pixel%s, dof off%s" % (
                     r["scene_file"], r["width"], r["height"], r["taps"],
                     " (AAEnabled as shipped: reference 5-tap AA)" if r["taps"] == 5 else "",
-                    "" if world == 1 else "; %d ranks x interleaved %d-row strips + RCCL gather to rank 0 (%s)" % (
-                        world, pipe.plan.strip_height, "double-buffered" if pipe.overlap else "serial")),
+                    "" if world == 1 else "; %d ranks x interleaved %d-row strips + RCCL gather to rank 0 (%s, %s strips)" % (
+                        world, pipe.plan.strip_height, "double-buffered" if pipe.overlap else "serial",
+                        "RGB32-encoded" if pipe.rgb32 else "float RGB")),
                 "name": args.workload,
                 "primary_rays_per_frame": r["primary"],
                 "shadow_rays_per_frame": r["shadow"],

@@ -171,6 +171,8 @@ C2RT_SYMBOLS = {
     "c2rt_render_pixel": (C.c_int, [_VP, _CAM_P, _OPTS_P, C.c_int, C.c_int, C.POINTER(TraceResult)]),
     "c2rt_deinterleave_strips": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
     "c2rt_encode_rgb32": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP]),
+    "c2rt_render_frame_rgb32": (C.c_int, [_VP, _CAM_P, _OPTS_P, _VP, _VP]),
+    "c2rt_deinterleave_strips_rgb32": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
 }
 
 # every symbol include/c2rt_host.h declares

@@ -191,6 +191,17 @@ class Context:
         self._check(self._lib.c2rt_deinterleave_strips(self._h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), width, height,
                                                        strip_height, world, C.c_void_p(stream)))
 
+    def renderFrameRGB32(self, cam, opts, stop_flag=None):
+        """Blocking render in display format: (local_rows, W) uint32 0x00RRGGBB (Color.toRGB32)."""
+        out = np.empty((self.localRows(opts), opts.width), dtype=np.uint32)
+        stop = stop_flag.ctypes.data_as(C.c_void_p) if stop_flag is not None else None
+        self._check(self._lib.c2rt_render_frame_rgb32(self._h, C.byref(cam), C.byref(opts), out.ctypes.data_as(C.c_void_p), stop))
+        return out
+
+    def deinterleaveStripsRGB32(self, gathered_ptr, frame_ptr, width, height, strip_height, world, stream=0):
+        self._check(self._lib.c2rt_deinterleave_strips_rgb32(self._h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), width, height,
+                                                             strip_height, world, C.c_void_p(stream)))
+
     def encodeRGB32(self, frame_ptr, out_ptr, n_pixels, stream=0):
         self._check(self._lib.c2rt_encode_rgb32(self._h, C.c_void_p(frame_ptr), C.c_void_p(out_ptr), int(n_pixels), C.c_void_p(stream)))
 

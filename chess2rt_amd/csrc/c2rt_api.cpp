@@ -623,8 +623,8 @@ int c2rt_render_pixel(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
     return C2RT_OK;
 }
 
-int c2rt_deinterleave_strips(c2rt_ctx *ctx, const float *gathered_dev, float *frame_dev, uint32_t width,
-                             uint32_t height, uint32_t strip_height, uint32_t world, void *hip_stream)
+static int deinterleave_words(c2rt_ctx *ctx, const float *gathered_dev, float *frame_dev, uint32_t width, uint32_t height,
+                              uint32_t strip_height, uint32_t world, uint32_t words_per_pixel, void *hip_stream)
 {
     if (!ctx) return C2RT_ERR_INVALID_ARG;
     if (!gathered_dev || !frame_dev || width == 0 || height == 0 || world == 0)
@@ -638,8 +638,49 @@ int c2rt_deinterleave_strips(c2rt_ctx *ctx, const float *gathered_dev, float *fr
     o.strip_world = world;
     const uint32_t sh = strip_h(&o);
     const uint32_t rows_pad = world > 1 ? local_rows_of(&o, 0) : height; /* rank 0 always owns the most rows */
-    const int e = launch_deinterleave(gathered_dev, frame_dev, width, height, sh, world, rows_pad, hip_stream);
+    const int e = launch_deinterleave(gathered_dev, frame_dev, width, height, sh, world, rows_pad, words_per_pixel, hip_stream);
     if (e != 0) return fail(ctx, C2RT_ERR_HIP, "de-interleave launch: %s", hipGetErrorString((hipError_t)e));
+    return C2RT_OK;
+}
+
+int c2rt_deinterleave_strips(c2rt_ctx *ctx, const float *gathered_dev, float *frame_dev, uint32_t width,
+                             uint32_t height, uint32_t strip_height, uint32_t world, void *hip_stream)
+{
+    return deinterleave_words(ctx, gathered_dev, frame_dev, width, height, strip_height, world, 3, hip_stream);
+}
+
+int c2rt_deinterleave_strips_rgb32(c2rt_ctx *ctx, const uint32_t *gathered_dev, uint32_t *frame_dev, uint32_t width,
+                                   uint32_t height, uint32_t strip_height, uint32_t world, void *hip_stream)
+{
+    return deinterleave_words(ctx, reinterpret_cast<const float *>(gathered_dev), reinterpret_cast<float *>(frame_dev), width,
+                              height, strip_height, world, 1, hip_stream);
+}
+
+int c2rt_render_frame_rgb32(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts,
+                            uint32_t *out_rgb32, const volatile uint8_t *stop_flag)
+{
+    int st = check_frame_args(ctx, cam, opts);
+    if (st != C2RT_OK) return st;
+    if (!out_rgb32) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
+    if (stop_flag && *stop_flag) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested before the frame");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t pixels = (size_t)c2rt_local_rows(opts) * opts->width;
+    /* staging: float frame followed by the packed frame */
+    const size_t floats = pixels * 3 + pixels;
+    if (floats > ctx->frame_floats) {
+        if (ctx->frame) { (void)hipFree(ctx->frame); ctx->frame = nullptr; ctx->frame_floats = 0; }
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->frame), floats * sizeof(float)));
+        ctx->frame_floats = floats;
+    }
+    uint32_t *packed = reinterpret_cast<uint32_t *>(ctx->frame + pixels * 3);
+    st = render_device(ctx, cam, opts, ctx->frame, ctx->stream);
+    if (st != C2RT_OK) return st;
+    if (pixels) {
+        const int e = launch_encode_rgb32(ctx->frame, packed, pixels, ctx->srgb_lut, ctx->stream);
+        if (e != 0) return fail(ctx, C2RT_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
+        HIP_TRY(ctx, hipMemcpyAsync(out_rgb32, packed, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return C2RT_OK;
 }
 

@@ -146,7 +146,7 @@ template <> int launch_render_level<4>(const RenderParams &, bool, void *);
 int launch_render(const RenderParams &p, const KernelVariant &v, void *stream);
 int launch_probe(const RenderParams &p, const KernelVariant &v, void *stream);
 int launch_deinterleave(const float *gathered, float *frame, uint32_t width, uint32_t height,
-                        uint32_t strip_height, uint32_t world, uint32_t rows_pad, void *stream);
+                        uint32_t strip_height, uint32_t world, uint32_t rows_pad, uint32_t words_per_pixel, void *stream);
 int launch_encode_rgb32(const float *frame, uint32_t *out, uint64_t n_pixels,
                         const uint8_t *lut_dev, void *stream);
 

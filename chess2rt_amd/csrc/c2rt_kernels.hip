@@ -1067,9 +1067,9 @@ int launch_probe(const RenderParams &p, const KernelVariant &, void *stream)
 }
 
 int launch_deinterleave(const float *gathered, float *frame, uint32_t width, uint32_t height,
-                        uint32_t strip_height, uint32_t world, uint32_t rows_pad, void *stream)
+                        uint32_t strip_height, uint32_t world, uint32_t rows_pad, uint32_t words_per_pixel, void *stream)
 {
-    const uint32_t row_floats = width * 3u;
+    const uint32_t row_floats = width * words_per_pixel; /* 3: float RGB, 1: packed RGB32 */
     const uint32_t per_row = (row_floats & 3u) == 0 ? row_floats / 4 : row_floats;
     const dim3 block(256), grid((per_row + 255) / 256 > 16 ? 16 : (per_row + 255) / 256, height);
     hipLaunchKernelGGL(deinterleave_kernel, grid, block, 0, static_cast<hipStream_t>(stream), gathered, frame,

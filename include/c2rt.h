@@ -282,6 +282,19 @@ int c2rt_deinterleave_strips(c2rt_ctx *ctx, const float *gathered_dev,
 int c2rt_encode_rgb32(c2rt_ctx *ctx, const float *frame_dev, uint32_t *out_dev,
                       uint64_t n_pixels, void *hip_stream);
 
+/* The frame in display format: render + the encode above on the device, then
+ * 4 B/pixel (instead of 12) over PCIe into the caller's host buffer — what
+ * SDL2Gui.draw (gui/sdl2_gui.d:139-155) computes per pixel on the CPU from the
+ * float frame.  Same blocking / stop-flag behaviour as c2rt_render_frame. */
+int c2rt_render_frame_rgb32(c2rt_ctx *ctx, const c2rt_camera_frame *cam,
+                            const c2rt_render_opts *opts, uint32_t *out_rgb32,
+                            const volatile uint8_t *stop_flag);
+
+/* c2rt_deinterleave_strips for packed RGB32 strips (one 32-bit word per pixel). */
+int c2rt_deinterleave_strips_rgb32(c2rt_ctx *ctx, const uint32_t *gathered_dev,
+                                   uint32_t *frame_dev, uint32_t width, uint32_t height,
+                                   uint32_t strip_height, uint32_t world, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

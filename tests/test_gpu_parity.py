@@ -460,3 +460,34 @@ def test_pathological_scenes_terminate_and_match(gpu_ctx, tmp_path):
             ref = orc.render_frame(scene.desc, cam, opts, 1)
             assert np.array_equal(np.isnan(a), np.isnan(ref)), name
             assert maxdiff(a, ref)[0] <= TOL, name
+
+
+def test_rgb32_frame_and_strips(gpu_ctx):
+    """Display-format output: render + Color.toRGB32 on the device, 4 B/pixel back to the host; packed strips
+    de-interleave like float ones."""
+    import torch
+
+    scene, cam, opts = load_config("lecture5_333x217_t4")
+    gpu_ctx.uploadScene(scene.desc)
+    W, H = opts.width, opts.height
+    flt = gpu_ctx.renderFrame(cam, opts)
+    packed = gpu_ctx.renderFrameRGB32(cam, opts)
+    assert packed.shape == (H, W) and packed.dtype == np.uint32
+    L = orc.lib()
+    rng = np.random.RandomState(2)
+    for _ in range(2000):
+        y, x = int(rng.randint(0, H)), int(rng.randint(0, W))
+        c = (C.c_float * 3)(*flt[y, x])
+        assert int(packed[y, x]) == L.orc_color_to_rgb32(c)
+    world = 3
+    plan = c2.plan_strips(H, world, 8)
+    gathered = torch.zeros((world, plan.rows_pad, W), dtype=torch.int32, device="cuda")
+    for r in range(world):
+        _, _, o = load_config("lecture5_333x217_t4", strip_height=8, strip_rank=r, strip_world=world)
+        part = gpu_ctx.renderFrameRGB32(cam, o)
+        assert np.array_equal(part, packed[[y for y in range(H) if (y // 8) % world == r]])
+        gathered[r, : part.shape[0]] = torch.from_numpy(part.astype(np.int32)).cuda()
+    frame = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    gpu_ctx.deinterleaveStripsRGB32(gathered.data_ptr(), frame.data_ptr(), W, H, 8, world, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy().astype(np.uint32), packed)
