@@ -8,7 +8,9 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -41,6 +43,11 @@ struct c2rt_ctx {
     uint32_t n_nodes = 0, n_lights = 0;
     float ambient[3] = {0, 0, 0};
     uint32_t max_trace_depth = 0;
+
+    /* world-space corners of every node's padded bounding box (for the per-frame
+     * screen rectangles); node_boxed[n] = 0: unbounded, never culled */
+    std::vector<double> node_box;  /* [n_nodes][8][3] */
+    std::vector<uint8_t> node_boxed;
 
     float *frame = nullptr;        /* staging frame for host-output renders */
     size_t frame_floats = 0;
@@ -221,6 +228,8 @@ int check_frame_args(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_ren
     return C2RT_OK;
 }
 
+void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t out[4]);
+
 void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *o, RenderParams &p)
 {
     std::memset(&p, 0, sizeof p);
@@ -251,6 +260,56 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
     p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
     p.blocks_x = (p.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     p.seed = o->seed;
+    p.n_cull = 0;
+    if (!cam->dof && cam->stereo_separation == 0 && !o->prepass_bucket) {
+        /* up to the last bounded node; nothing bounded => no per-wave work at all */
+        const uint32_t lim = ctx->n_nodes < (uint32_t)kMaxCullNodes ? ctx->n_nodes : (uint32_t)kMaxCullNodes;
+        for (uint32_t n = 0; n < lim; ++n)
+            if (ctx->node_boxed[n]) p.n_cull = n + 1;
+        for (uint32_t n = 0; n < p.n_cull; ++n) {
+            if (ctx->node_boxed[n]) cull_rect_of(cam, &ctx->node_box[(size_t)n * 24], p.cull_rect[n]);
+            else { p.cull_rect[n][0] = p.cull_rect[n][1] = INT32_MIN; p.cull_rect[n][2] = p.cull_rect[n][3] = INT32_MAX; }
+        }
+    }
+}
+
+/* Screen rectangle of a node for this frame: the projection of the 8 world-space
+ * box corners through the camera (a projective map, convex on the half space in
+ * front of the eye), widened by 2 pixels (the AA taps reach 0.6 px, rounding is
+ * ~1e-13 px).  Any corner at or behind the eye plane => the whole frame. */
+void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t out[4])
+{
+    const int32_t kAll[4] = {INT32_MIN, INT32_MIN, INT32_MAX, INT32_MAX};
+    std::memcpy(out, kAll, sizeof kAll);
+    double du[3], dv[3], ul[3];
+    for (int i = 0; i < 3; ++i) {
+        du[i] = cam->up_right[i] - cam->up_left[i];
+        dv[i] = cam->down_left[i] - cam->up_left[i];
+        ul[i] = cam->up_left[i] - cam->pos[i];
+    }
+    /* solve a*du + b*dv + l*ul = w by Cramer's rule */
+    auto det3 = [](const double *a, const double *b, const double *c) {
+        return a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+    };
+    const double det = det3(du, dv, ul);
+    if (!std::isfinite(det) || det == 0) return;
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int k = 0; k < 8; ++k) {
+        double w[3];
+        for (int i = 0; i < 3; ++i) w[i] = corners[3 * k + i] - cam->pos[i];
+        const double a = det3(w, dv, ul) / det, b = det3(du, w, ul) / det, l = det3(du, dv, w) / det;
+        if (!(l > 1e-9) || !std::isfinite(a) || !std::isfinite(b)) return; /* at / behind the eye: no culling */
+        const double px = a / l * cam->frame_width, py = b / l * cam->frame_height;
+        if (!std::isfinite(px) || !std::isfinite(py)) return;
+        xmin = std::fmin(xmin, px); xmax = std::fmax(xmax, px);
+        ymin = std::fmin(ymin, py); ymax = std::fmax(ymax, py);
+    }
+    const double lim = 1e9;
+    if (xmin < -lim || ymin < -lim || xmax > lim || ymax > lim) return;
+    out[0] = (int32_t)std::floor(xmin) - 2;
+    out[1] = (int32_t)std::floor(ymin) - 2;
+    out[2] = (int32_t)std::ceil(xmax) + 3;
+    out[3] = (int32_t)std::ceil(ymax) + 3;
 }
 
 KernelVariant variant_of(const c2rt_ctx *ctx, const c2rt_camera_frame *cam)
@@ -465,6 +524,26 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         for (int i = 0; i < 9; ++i) ident = ident && d.m[i] == I[i] && d.inv[i] == I[i] && d.tinv[i] == I[i];
         if (ident) d.flags |= kNodeIdentityMatrix;
         if (d.off[0] == 0 && d.off[1] == 0 && d.off[2] == 0) d.flags |= kNodeZeroOffset;
+    }
+
+    /* world-space bounding boxes of the nodes: object-space bounding sphere -> its
+     * axis-aligned box -> the 8 corners through Transform.point (affine: hull preserved) */
+    ctx->node_box.assign((size_t)s->n_nodes * 24, 0.0);
+    ctx->node_boxed.assign(s->n_nodes, 0);
+    for (uint32_t n = 0; n < s->n_nodes; ++n) {
+        const DevGeom &g = nodes[n].g;
+        if (!(g.flags & kGeomBounded)) continue;
+        const double r = std::sqrt(g.bound[3]);
+        bool finite = std::isfinite(r);
+        for (int k = 0; k < 8 && finite; ++k) {
+            const double q[3] = {g.bound[0] + ((k & 1) ? r : -r), g.bound[1] + ((k & 2) ? r : -r), g.bound[2] + ((k & 4) ? r : -r)};
+            double *w = &ctx->node_box[((size_t)n * 8 + k) * 3];
+            for (int j = 0; j < 3; ++j) {
+                w[j] = q[0] * nodes[n].m[0 + j] + q[1] * nodes[n].m[3 + j] + q[2] * nodes[n].m[6 + j] + nodes[n].off[j];
+                finite = finite && std::isfinite(w[j]);
+            }
+        }
+        ctx->node_boxed[n] = finite ? 1 : 0;
     }
 
     int st;

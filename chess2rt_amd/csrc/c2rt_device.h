@@ -24,6 +24,7 @@ constexpr int kCsgEntries = 2 * kMaxCsgHits;
 #endif
 constexpr int kTileW = C2RT_TILE_W, kTileH = 64 / C2RT_TILE_W; /* one wavefront = one 8x8 pixel tile */
 constexpr int kWave = 64;
+constexpr int kMaxCullNodes = 32;  /* nodes beyond this are always tested */
 #ifndef C2RT_WAVES_PER_BLOCK
 #define C2RT_WAVES_PER_BLOCK 1
 #endif
@@ -118,6 +119,12 @@ struct RenderParams {
     uint32_t strip_height, strip_rank, strip_world;
     uint32_t local_rows;           /* rows this launch renders */
     uint32_t row_offset;           /* first local row of this launch (chunked host-output renders) */
+    /* Per-frame screen-space culling of PRIMARY rays (host-computed, c2rt_api.cpp):
+     * the pixel rectangle [x0, x1) x [y0, y1) outside of which no ray through a
+     * sample of this frame can reach node n's padded bounding box.  n_cull = 0
+     * disables it (depth of field, stereo, prepass). */
+    uint32_t n_cull;
+    int32_t cull_rect[kMaxCullNodes][4];
     uint32_t tiles_x, tiles_y;     /* tile grid over the LOCAL rows */
     uint32_t blocks_x;             /* ceil(tiles_x / kWavesPerBlock) */
     uint64_t seed;

@@ -146,6 +146,7 @@ struct Ctx {
     uint32_t n_nodes;
     char *lds;        /* this wave's CSG slabs */
     int lane;
+    uint32_t primary_mask; /* bit n clear: no primary ray of this tile can reach node n (wave-uniform) */
 };
 
 /* A ray in some object space: origin, unit direction and A = |d|^2 exactly as
@@ -793,8 +794,10 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt,
     best.axis_n = false;
     int closest = -1;
     const uint32_t nn = P.n_nodes;
-    for (uint32_t n = 0; n < nn; ++n)
+    for (uint32_t n = 0; n < nn; ++n) {
+        if (n < (uint32_t)kMaxCullNodes && !((cx.primary_mask >> n) & 1u)) continue; /* scalar branch */
         if (node_intersect<LEVELS, kFull>(cx, P.nodes + n, ray, best)) closest = (int)n;
+    }
     /* Sphere u,v are read only by textured shaders (and the probe) */
     if (closest >= 0 && best.uv_pending && (probe || P.shaders[P.nodes[closest].shader].tex >= 0)) finish_uv(best);
     if (probe) {
@@ -918,6 +921,30 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     cx.n_nodes = P.n_nodes;
     cx.lds = lds;
     cx.lane = lane;
+    /* which nodes can the primary rays of this tile reach?  Frame-space tile
+     * rectangle against the host's per-node rectangles: scalar compares only. */
+    cx.primary_mask = 0xFFFFFFFFu;
+    if constexpr (!DOF) {
+        if (P.n_cull) {
+            const int tx0 = (int)(tcol * kTileW), tx1 = tx0 + kTileW;
+            const uint32_t lr_first = trow * kTileH + P.row_offset;
+            uint32_t lr_last = trow * kTileH + kTileH - 1;
+            if (lr_last >= P.local_rows) lr_last = P.local_rows - 1;
+            lr_last += P.row_offset;
+            int ty0 = (int)lr_first, ty1 = (int)lr_last;
+            if (P.strip_world > 1) { /* the strip map is monotonic in the local row */
+                const uint32_t sh = P.strip_height;
+                ty0 = (int)(((lr_first / sh) * P.strip_world + P.strip_rank) * sh + lr_first % sh);
+                ty1 = (int)(((lr_last / sh) * P.strip_world + P.strip_rank) * sh + lr_last % sh);
+            }
+            uint32_t mask = 0xFFFFFFFFu;
+            for (uint32_t n = 0; n < P.n_cull; ++n) {
+                const int *r = P.cull_rect[n];
+                if (r[2] <= tx0 || r[0] >= tx1 || r[3] <= ty0 || r[1] > ty1) mask &= ~(1u << n);
+            }
+            cx.primary_mask = mask;
+        }
+    }
     Counters cnt = {0, 0};
     /* prepassOnly (rt/renderer.d:110-130): the pixel shows the sample of the
      * top-left pixel of its 16x16 block inside its bucket */
@@ -965,6 +992,7 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.n_nodes = P.n_nodes;
     cx.lds = lds;
     cx.lane = 0;
+    cx.primary_mask = 0xFFFFFFFFu;
     Counters cnt = {0, 0};
     const uint64_t pixel = (uint64_t)P.probe_y * P.width + (uint64_t)P.probe_x;
     const F3 c = render_sample<LEVELS, DOF>(P, cx, (double)P.probe_x, (double)P.probe_y, pixel, 0, cnt, P.probe_out);
