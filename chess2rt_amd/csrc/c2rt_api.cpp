@@ -47,6 +47,7 @@ struct c2rt_ctx {
     /* world-space corners of every node's padded bounding box (for the per-frame
      * screen rectangles); node_boxed[n] = 0: unbounded, never culled */
     std::vector<double> node_box;  /* [n_nodes][8][3] */
+    std::vector<double> light_pos; /* [n_lights][3] host copy for the per-frame shadow-cull thresholds */
     std::vector<uint8_t> node_boxed;
 
     float *frame = nullptr;        /* staging frame for host-output renders */
@@ -229,6 +230,7 @@ int check_frame_args(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_ren
 }
 
 void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t out[4]);
+void light_side_of(const c2rt_camera_frame *cam, const double *light, int32_t out[8]);
 
 void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *o, RenderParams &p)
 {
@@ -270,6 +272,10 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
             if (ctx->node_boxed[n]) cull_rect_of(cam, &ctx->node_box[(size_t)n * 24], p.cull_rect[n]);
             else { p.cull_rect[n][0] = p.cull_rect[n][1] = INT32_MIN; p.cull_rect[n][2] = p.cull_rect[n][3] = INT32_MAX; }
         }
+        if (p.n_cull) {
+            p.n_cull_lights = ctx->n_lights < (uint32_t)kMaxCullLights ? ctx->n_lights : (uint32_t)kMaxCullLights;
+            for (uint32_t l = 0; l < p.n_cull_lights; ++l) light_side_of(cam, &ctx->light_pos[3 * (size_t)l], p.light_side[l]);
+        }
     }
 }
 
@@ -310,6 +316,51 @@ void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t o
     out[1] = (int32_t)std::floor(ymin) - 2;
     out[2] = (int32_t)std::ceil(xmax) + 3;
     out[3] = (int32_t)std::ceil(ymax) + 3;
+}
+
+/* For one light: the integer boundary coordinates x (pixels) for which the light is
+ * certainly in the closed half space a - l*x/W >= 0 (">= x" side of the vertical
+ * boundary plane through the eye) resp. <= 0, and the same for y.  (a, b, l) are
+ * the light's coordinates in the (du, dv, ul) basis; the half spaces are linear in
+ * them, so this is valid for lights behind the eye too.  One pixel of slack. */
+void light_side_of(const c2rt_camera_frame *cam, const double *light, int32_t out[8])
+{
+    for (int i = 0; i < 4; ++i) { out[2 * i] = 1; out[2 * i + 1] = 0; } /* empty intervals */
+    double du[3], dv[3], ul[3], w[3];
+    for (int i = 0; i < 3; ++i) {
+        du[i] = cam->up_right[i] - cam->up_left[i];
+        dv[i] = cam->down_left[i] - cam->up_left[i];
+        ul[i] = cam->up_left[i] - cam->pos[i];
+        w[i] = light[i] - cam->pos[i];
+    }
+    auto det3 = [](const double *a, const double *b, const double *c) {
+        return a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+    };
+    const double det = det3(du, dv, ul);
+    if (!std::isfinite(det) || det == 0) return;
+    const double a = det3(w, dv, ul) / det, b = det3(du, w, ul) / det, l = det3(du, dv, w) / det;
+    if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(l)) return;
+    const double lim = 1e9;
+    auto axis = [&](double c, double size, int32_t *ge, int32_t *le) {
+        /* phi(x) = c*size - l*x: ">= x side" <=> phi(x) >= 0, "<= x side" <=> phi(x) <= 0 */
+        const double eps = 1e-12 * (std::fabs(c) + std::fabs(l));
+        if (std::fabs(l) <= eps) {
+            if (c > eps) { ge[0] = INT32_MIN; ge[1] = INT32_MAX; }
+            if (c < -eps) { le[0] = INT32_MIN; le[1] = INT32_MAX; }
+            return;
+        }
+        const double xs = c * size / l;
+        if (!(std::fabs(xs) < lim)) return;
+        if (l > 0) { /* phi decreasing: >= 0 for x <= xs */
+            ge[0] = INT32_MIN; ge[1] = (int32_t)std::floor(xs) - 1;
+            le[0] = (int32_t)std::ceil(xs) + 1; le[1] = INT32_MAX;
+        } else {     /* phi increasing: >= 0 for x >= xs */
+            ge[0] = (int32_t)std::ceil(xs) + 1; ge[1] = INT32_MAX;
+            le[0] = INT32_MIN; le[1] = (int32_t)std::floor(xs) - 1;
+        }
+    };
+    axis(a, cam->frame_width, out + 0, out + 2);
+    axis(b, cam->frame_height, out + 4, out + 6);
 }
 
 KernelVariant variant_of(const c2rt_ctx *ctx, const c2rt_camera_frame *cam)
@@ -533,7 +584,18 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
     for (uint32_t n = 0; n < s->n_nodes; ++n) {
         const DevGeom &g = nodes[n].g;
         if (!(g.flags & kGeomBounded)) continue;
-        const double r = std::sqrt(g.bound[3]);
+        /* a singular / non-finite transform (e.g. `scale 0 0 0`) sends NaN rays into the
+         * geometry, whose hits follow no geometric bound: never cull such a node */
+        bool sane = true;
+        for (int i = 0; i < 9; ++i) sane = sane && std::isfinite(nodes[n].m[i]) && std::isfinite(nodes[n].inv[i]) && std::isfinite(nodes[n].tinv[i]);
+        for (int i = 0; i < 3; ++i) sane = sane && std::isfinite(nodes[n].off[i]);
+        if (!sane) continue;
+        /* shadow rays start 1e-6 (world units) off the surface (rt/shader.d:88): pad by
+         * 4e-6 world units = 4e-6 * |M^-1|_F object units (|M^-1|_F >= 1 / smallest scale) */
+        double inv_norm = 0;
+        for (int i = 0; i < 9; ++i) inv_norm += nodes[n].inv[i] * nodes[n].inv[i];
+        inv_norm = std::sqrt(inv_norm);
+        const double r = std::sqrt(g.bound[3]) + 4e-6 * (inv_norm > 1 ? inv_norm : 1.0);
         bool finite = std::isfinite(r);
         for (int k = 0; k < 8 && finite; ++k) {
             const double q[3] = {g.bound[0] + ((k & 1) ? r : -r), g.bound[1] + ((k & 2) ? r : -r), g.bound[2] + ((k & 4) ? r : -r)};
@@ -545,6 +607,8 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         }
         ctx->node_boxed[n] = finite ? 1 : 0;
     }
+
+    ctx->light_pos.assign(s->light_pos, s->light_pos + 3 * (size_t)s->n_lights);
 
     int st;
     if ((st = upload(ctx, &ctx->geoms, geoms)) != C2RT_OK) return st;

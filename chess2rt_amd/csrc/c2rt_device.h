@@ -25,6 +25,7 @@ constexpr int kCsgEntries = 2 * kMaxCsgHits;
 constexpr int kTileW = C2RT_TILE_W, kTileH = 64 / C2RT_TILE_W; /* one wavefront = one 8x8 pixel tile */
 constexpr int kWave = 64;
 constexpr int kMaxCullNodes = 32;  /* nodes beyond this are always tested */
+constexpr int kMaxCullLights = 4;  /* lights beyond this get no shadow-ray culling */
 #ifndef C2RT_WAVES_PER_BLOCK
 #define C2RT_WAVES_PER_BLOCK 1
 #endif
@@ -125,6 +126,15 @@ struct RenderParams {
      * disables it (depth of field, stereo, prepass). */
     uint32_t n_cull;
     int32_t cull_rect[kMaxCullNodes][4];
+    /* SHADOW rays: all hit points of a tile lie inside the tile's view pyramid; a
+     * node whose box is entirely beyond one side plane of that pyramid while the
+     * light is on the inner side of the same plane cannot occlude any of the
+     * tile's shadow rays.  Per light, the tile-boundary coordinates for which the
+     * light is certainly on the ">= x" / "<= x" side of the vertical boundary
+     * plane x (same for y), as closed integer intervals (empty when lo > hi):
+     * [0..1] ">= x" lo,hi  [2..3] "<= x" lo,hi  [4..5] ">= y"  [6..7] "<= y". */
+    uint32_t n_cull_lights;
+    int32_t light_side[kMaxCullLights][8];
     uint32_t tiles_x, tiles_y;     /* tile grid over the LOCAL rows */
     uint32_t blocks_x;             /* ceil(tiles_x / kWavesPerBlock) */
     uint64_t seed;

@@ -147,6 +147,7 @@ struct Ctx {
     char *lds;        /* this wave's CSG slabs */
     int lane;
     uint32_t primary_mask; /* bit n clear: no primary ray of this tile can reach node n (wave-uniform) */
+    uint32_t shadow_mask[kMaxCullLights]; /* same for the tile's shadow rays towards light l */
 };
 
 /* A ray in some object space: origin, unit direction and A = |d|^2 exactly as
@@ -619,15 +620,17 @@ DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &b
 
 /* Scene.testVisibility — rt/scene.d:62-78 */
 template <int LEVELS>
-DEV bool test_visibility(const Ctx &cx, D3 from, D3 to)
+DEV bool test_visibility(const Ctx &cx, D3 from, D3 to, uint32_t node_mask)
 {
     const D3 dir = normalized(to - from);
     const RayW ray = make_ray(from, dir);
     Hit temp;
     temp.dist = mag(to - from);
     const uint32_t nn = cx.n_nodes;
-    for (uint32_t n = 0; n < nn; ++n)
+    for (uint32_t n = 0; n < nn; ++n) {
+        if (n < (uint32_t)kMaxCullNodes && !((node_mask >> n) & 1u)) continue; /* scalar branch */
         if (node_intersect<LEVELS, kBool>(cx, cx.nodes + n, ray, temp)) return false;
+    }
     return true;
 }
 
@@ -704,7 +707,7 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, int shader, D3 rd, const Hit 
         if (L->lit) {
             const D3 lightPos = ld3(L->pos);
             shadow_rays += 1;
-            if (test_visibility<LEVELS>(cx, h.p + N * 1e-6, lightPos)) {
+            if (test_visibility<LEVELS>(cx, h.p + N * 1e-6, lightPos, l < (uint32_t)kMaxCullLights ? cx.shadow_mask[l] : 0xFFFFFFFFu)) {
                 const F3 lightColor = ldf3(L->color);
                 const D3 lightDir = normalized(lightPos - h.p);
                 const double cosTheta = dot(lightDir, N);
@@ -903,6 +906,53 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     if (trow >= P.tiles_y) return;
     const uint32_t tcol = bcol * kWavesPerBlock + wave;
 
+    /* Which nodes can this tile's primary rays reach, and which can occlude its
+     * shadow rays towards light l?  The host supplies one pixel rectangle per node
+     * and the side intervals of every light (RenderParams); lane n tests node n
+     * and a ballot makes the wave-uniform masks — before any lane leaves, so that
+     * every node has its lane. */
+    uint32_t pmask = 0xFFFFFFFFu;
+    uint32_t smask[kMaxCullLights];
+#pragma unroll
+    for (int l = 0; l < kMaxCullLights; ++l) smask[l] = 0xFFFFFFFFu;
+    if constexpr (!DOF) {
+        if (P.n_cull) {
+            const int tx0 = (int)(tcol * kTileW), tx1 = tx0 + kTileW;
+            const uint32_t lr_first = trow * kTileH + P.row_offset;
+            uint32_t lr_last = trow * kTileH + kTileH - 1;
+            if (lr_last >= P.local_rows) lr_last = P.local_rows - 1;
+            lr_last += P.row_offset;
+            int ty0 = (int)lr_first, ty1 = (int)lr_last;
+            if (P.strip_world > 1) { /* the strip map is monotonic in the local row */
+                const uint32_t sh = P.strip_height;
+                ty0 = (int)(((lr_first / sh) * P.strip_world + P.strip_rank) * sh + lr_first % sh);
+                ty1 = (int)(((lr_last / sh) * P.strip_world + P.strip_rank) * sh + lr_last % sh);
+            }
+            /* the rectangles live in the kernel-argument segment: a per-lane load from it */
+            typedef const int __attribute__((address_space(4))) *KInt;
+            KInt rects = (KInt)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() +
+                                __builtin_offsetof(RenderParams, cull_rect));
+            const bool mine = (uint32_t)lane < P.n_cull; /* lanes >= n_cull stand for "always test" */
+            const int ln = mine ? lane : 0;
+            const int r0 = rects[4 * ln + 0], r1 = rects[4 * ln + 1], r2 = rects[4 * ln + 2], r3 = rects[4 * ln + 3];
+            const bool seen = !mine || !(r2 <= tx0 || r0 >= tx1 || r3 <= ty0 || r1 > ty1);
+            pmask = (uint32_t)__ballot(seen);
+            /* sample coordinates of this tile: x in [tx0, tx0 + 8.6), y in [ty0, ty1 + 0.6] */
+            const int sx1 = tx1 + 1, sy1 = ty1 + 1;
+#pragma unroll
+            for (int l = 0; l < kMaxCullLights; ++l) {
+                if ((uint32_t)l >= P.n_cull_lights) break;
+                const int *sd = P.light_side[l];
+                const bool in_left = tx0 >= sd[0] && tx0 <= sd[1];   /* light on the ">= tx0" side of the left plane */
+                const bool in_right = sx1 >= sd[2] && sx1 <= sd[3];  /* light on the "<= sx1" side of the right plane */
+                const bool in_top = ty0 >= sd[4] && ty0 <= sd[5];
+                const bool in_bottom = sy1 >= sd[6] && sy1 <= sd[7];
+                const bool culled = mine && ((in_left && r2 <= tx0) || (in_right && r0 >= sx1) || (in_top && r3 <= ty0) || (in_bottom && r1 >= sy1));
+                smask[l] = (uint32_t)__ballot(!culled);
+            }
+        }
+    }
+
     const uint32_t x = tcol * kTileW + (lane % kTileW);
     const uint32_t lr0 = trow * kTileH + (lane / kTileW); /* row within this launch */
     if (x >= P.width || lr0 >= P.local_rows) return;
@@ -921,30 +971,9 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     cx.n_nodes = P.n_nodes;
     cx.lds = lds;
     cx.lane = lane;
-    /* which nodes can the primary rays of this tile reach?  Frame-space tile
-     * rectangle against the host's per-node rectangles: scalar compares only. */
-    cx.primary_mask = 0xFFFFFFFFu;
-    if constexpr (!DOF) {
-        if (P.n_cull) {
-            const int tx0 = (int)(tcol * kTileW), tx1 = tx0 + kTileW;
-            const uint32_t lr_first = trow * kTileH + P.row_offset;
-            uint32_t lr_last = trow * kTileH + kTileH - 1;
-            if (lr_last >= P.local_rows) lr_last = P.local_rows - 1;
-            lr_last += P.row_offset;
-            int ty0 = (int)lr_first, ty1 = (int)lr_last;
-            if (P.strip_world > 1) { /* the strip map is monotonic in the local row */
-                const uint32_t sh = P.strip_height;
-                ty0 = (int)(((lr_first / sh) * P.strip_world + P.strip_rank) * sh + lr_first % sh);
-                ty1 = (int)(((lr_last / sh) * P.strip_world + P.strip_rank) * sh + lr_last % sh);
-            }
-            uint32_t mask = 0xFFFFFFFFu;
-            for (uint32_t n = 0; n < P.n_cull; ++n) {
-                const int *r = P.cull_rect[n];
-                if (r[2] <= tx0 || r[0] >= tx1 || r[3] <= ty0 || r[1] > ty1) mask &= ~(1u << n);
-            }
-            cx.primary_mask = mask;
-        }
-    }
+    cx.primary_mask = pmask;
+#pragma unroll
+    for (int l = 0; l < kMaxCullLights; ++l) cx.shadow_mask[l] = smask[l];
     Counters cnt = {0, 0};
     /* prepassOnly (rt/renderer.d:110-130): the pixel shows the sample of the
      * top-left pixel of its 16x16 block inside its bucket */
@@ -993,6 +1022,7 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.lds = lds;
     cx.lane = 0;
     cx.primary_mask = 0xFFFFFFFFu;
+    for (int l = 0; l < kMaxCullLights; ++l) cx.shadow_mask[l] = 0xFFFFFFFFu;
     Counters cnt = {0, 0};
     const uint64_t pixel = (uint64_t)P.probe_y * P.width + (uint64_t)P.probe_x;
     const F3 c = render_sample<LEVELS, DOF>(P, cx, (double)P.probe_x, (double)P.probe_y, pixel, 0, cnt, P.probe_out);
