@@ -755,6 +755,8 @@ int c2rt_render_pixel(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     RenderParams p;
     fill_params(ctx, cam, opts, p);
+    p.n_cull = 0; /* the probe launch has no tile: never cull */
+    p.n_cull_lights = 0;
     p.probe_x = x;
     p.probe_y = y;
     p.probe_out = ctx->probe;

@@ -25,7 +25,10 @@ constexpr int kCsgEntries = 2 * kMaxCsgHits;
 constexpr int kTileW = C2RT_TILE_W, kTileH = 64 / C2RT_TILE_W; /* one wavefront = one 8x8 pixel tile */
 constexpr int kWave = 64;
 constexpr int kMaxCullNodes = 32;  /* nodes beyond this are always tested */
-constexpr int kMaxCullLights = 4;  /* lights beyond this get no shadow-ray culling */
+#ifndef C2RT_MAX_CULL_LIGHTS
+#define C2RT_MAX_CULL_LIGHTS 4
+#endif
+constexpr int kMaxCullLights = C2RT_MAX_CULL_LIGHTS; /* lights beyond this get no shadow-ray culling */
 #ifndef C2RT_WAVES_PER_BLOCK
 #define C2RT_WAVES_PER_BLOCK 1
 #endif

@@ -147,7 +147,7 @@ struct Ctx {
     char *lds;        /* this wave's CSG slabs */
     int lane;
     uint32_t primary_mask; /* bit n clear: no primary ray of this tile can reach node n (wave-uniform) */
-    uint32_t shadow_mask[kMaxCullLights]; /* same for the tile's shadow rays towards light l */
+    uint32_t shadow_mask0; /* same for the tile's shadow rays towards light 0 (further lights: shadow_cull_mask) */
 };
 
 /* A ray in some object space: origin, unit direction and A = |d|^2 exactly as
@@ -618,6 +618,75 @@ DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &b
     return true;
 }
 
+/* ------------------------------------------------------------------ */
+/* per-frame culling masks (host-computed rectangles, RenderParams)      */
+/* ------------------------------------------------------------------ */
+
+/* Frame-space pixel bounds of this wave's tile: x in [tx0, tx0 + 8), rows
+ * ty0..ty1 (the strip map is monotonic in the local row). */
+DEV void tile_bounds(const RenderParams &P, int &tx0, int &ty0, int &ty1)
+{
+    const uint32_t b = blockIdx.x;
+#if C2RT_XCD_SWIZZLE
+    const uint32_t xcd = b & 7u, j = b >> 3;
+    const uint32_t trow = (j / P.blocks_x) * 8u + xcd, bcol = j % P.blocks_x;
+#else
+    const uint32_t trow = b / P.blocks_x, bcol = b % P.blocks_x;
+#endif
+    const uint32_t tcol = bcol * kWavesPerBlock + threadIdx.x / kWave;
+    tx0 = (int)(tcol * kTileW);
+    const uint32_t lr_first = trow * kTileH + P.row_offset;
+    uint32_t lr_last = trow * kTileH + kTileH - 1;
+    if (lr_last >= P.local_rows) lr_last = P.local_rows - 1;
+    lr_last += P.row_offset;
+    ty0 = (int)lr_first;
+    ty1 = (int)lr_last;
+    if (P.strip_world > 1) {
+        const uint32_t sh = P.strip_height;
+        ty0 = (int)(((lr_first / sh) * P.strip_world + P.strip_rank) * sh + lr_first % sh);
+        ty1 = (int)(((lr_last / sh) * P.strip_world + P.strip_rank) * sh + lr_last % sh);
+    }
+}
+
+/* this lane's node rectangle (lane n stands for node n), read from the kernel-argument segment */
+DEV void lane_rect(const RenderParams &P, int lane, bool &mine, int &r0, int &r1, int &r2, int &r3)
+{
+    typedef const int __attribute__((address_space(4))) *KInt;
+    KInt rects = (KInt)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() +
+                        __builtin_offsetof(RenderParams, cull_rect));
+    mine = (uint32_t)lane < P.n_cull; /* lanes >= n_cull stand for "always test" */
+    const int ln = mine ? lane : 0;
+    r0 = rects[4 * ln + 0];
+    r1 = rects[4 * ln + 1];
+    r2 = rects[4 * ln + 2];
+    r3 = rects[4 * ln + 3];
+}
+
+/* Nodes that may occlude this tile's shadow rays towards light l: every hit point
+ * lies in the tile's view pyramid; a node whose box is entirely beyond one side
+ * plane of the pyramid while the light is on the inner side of that plane is in a
+ * half space none of those segments enters.  Lanes that are not active (missed,
+ * left the frame) cannot vote: their nodes stay "may occlude". */
+DEV uint32_t shadow_cull_mask(const RenderParams &P, int lane, uint32_t l)
+{
+    if (!P.n_cull || l >= P.n_cull_lights) return 0xFFFFFFFFu;
+    int tx0, ty0, ty1;
+    tile_bounds(P, tx0, ty0, ty1);
+    /* sample coordinates of this tile: x in [tx0, tx0 + 8.6), y in [ty0, ty1 + 0.6] */
+    const int sx1 = tx0 + kTileW + 1, sy1 = ty1 + 1;
+    bool mine;
+    int r0, r1, r2, r3;
+    lane_rect(P, lane, mine, r0, r1, r2, r3);
+    const int *sd = P.light_side[l];
+    const bool in_left = tx0 >= sd[0] && tx0 <= sd[1];   /* light on the ">= tx0" side of the left plane */
+    const bool in_right = sx1 >= sd[2] && sx1 <= sd[3];  /* light on the "<= sx1" side of the right plane */
+    const bool in_top = ty0 >= sd[4] && ty0 <= sd[5];
+    const bool in_bottom = sy1 >= sd[6] && sy1 <= sd[7];
+    const bool culled = mine && ((in_left && r2 <= tx0) || (in_right && r0 >= sx1) || (in_top && r3 <= ty0) || (in_bottom && r1 >= sy1));
+    const unsigned long long active = __ballot(true);
+    return (uint32_t)__ballot(!culled) | ~(uint32_t)active;
+}
+
 /* Scene.testVisibility — rt/scene.d:62-78 */
 template <int LEVELS>
 DEV bool test_visibility(const Ctx &cx, D3 from, D3 to, uint32_t node_mask)
@@ -690,7 +759,10 @@ DEV F3 tex_color(const RenderParams &P, int tex, double u, double v)
 /* shading — rt/shader.d:67-105,197-250                                  */
 /* ------------------------------------------------------------------ */
 
-template <int LEVELS>
+/* MLC ("multi-light culling"): scenes with more than one light also derive the
+ * culling mask of lights 1.. (per sample); single-light scenes run the instance
+ * without that code. */
+template <int LEVELS, bool MLC>
 DEV F3 shade(const RenderParams &P, const Ctx &cx, int shader, D3 rd, const Hit &h, uint32_t &shadow_rays)
 {
     const DevShader *S = P.shaders + shader;
@@ -707,7 +779,7 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, int shader, D3 rd, const Hit 
         if (L->lit) {
             const D3 lightPos = ld3(L->pos);
             shadow_rays += 1;
-            if (test_visibility<LEVELS>(cx, h.p + N * 1e-6, lightPos, l < (uint32_t)kMaxCullLights ? cx.shadow_mask[l] : 0xFFFFFFFFu)) {
+            if (test_visibility<LEVELS>(cx, h.p + N * 1e-6, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.lane, l) : 0xFFFFFFFFu))) {
                 const F3 lightColor = ldf3(L->color);
                 const D3 lightDir = normalized(lightPos - h.p);
                 const double cosTheta = dot(lightDir, N);
@@ -783,7 +855,7 @@ DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &
 struct Counters { uint32_t primary, shadow; };
 
 /* trace + raytrace_impl — rt/renderer.d:325-376 (primary rays have depth 0) */
-template <int LEVELS>
+template <int LEVELS, bool MLC>
 DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt, c2rt_trace_result *probe)
 {
     cnt.primary += 1;
@@ -813,7 +885,7 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt,
         probe->ray_dir[0] = d.x; probe->ray_dir[1] = d.y; probe->ray_dir[2] = d.z;
     }
     if (closest < 0) return mkf(0, 0, 0); /* Environment.getEnvironment — rt/environment.d:7-10 */
-    return shade<LEVELS>(P, cx, P.nodes[closest].shader, d, best, cnt.shadow);
+    return shade<LEVELS, MLC>(P, cx, P.nodes[closest].shader, d, best, cnt.shadow);
 }
 
 /* adjustSaturation + combineStereo — rt/color.d:10-15,77-83 */
@@ -830,7 +902,7 @@ DEV F3 combine_stereo(F3 l, F3 r)
 }
 
 /* renderSample — rt/renderer.d:254-313 */
-template <int LEVELS, bool DOF>
+template <int LEVELS, bool DOF, bool MLC>
 DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, uint64_t pixel, uint32_t tap,
                      Counters &cnt, c2rt_trace_result *probe)
 {
@@ -838,7 +910,7 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
     D3 o, d;
     if constexpr (!DOF) {
         screen_ray<false>(P, x, y, 0, rng, o, d);
-        return raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+        return raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
     } else {
         const bool stereo = P.cam.stereo_separation != 0;
         if (P.cam.dof) {
@@ -850,13 +922,13 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
                 double jx = rng_next(rng), jy = rng_next(rng);
                 if (!stereo) {
                     screen_ray<true>(P, x + jx * 1, y + jy * 1, 0, rng, o, d);
-                    average = average + raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+                    average = average + raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
                 } else {
                     screen_ray<true>(P, x + jx * 1, y + jy * 1, -1, rng, o, d);
-                    const F3 l = raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+                    const F3 l = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
                     jx = rng_next(rng), jy = rng_next(rng);
                     screen_ray<true>(P, x + jx * 1, y + jy * 1, +1, rng, o, d);
-                    const F3 r = raytrace<LEVELS>(P, cx, o, d, cnt, nullptr);
+                    const F3 r = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, nullptr);
                     average = average + combine_stereo(l, r);
                 }
             }
@@ -864,12 +936,12 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
         }
         if (!stereo) {
             screen_ray<true>(P, x, y, 0, rng, o, d);
-            return raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+            return raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
         }
         screen_ray<true>(P, x, y, -1, rng, o, d);
-        const F3 l = raytrace<LEVELS>(P, cx, o, d, cnt, probe);
+        const F3 l = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
         screen_ray<true>(P, x, y, +1, rng, o, d);
-        const F3 r = raytrace<LEVELS>(P, cx, o, d, cnt, nullptr);
+        const F3 r = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, nullptr);
         return combine_stereo(l, r);
     }
 }
@@ -884,7 +956,7 @@ __constant__ double k_aa_y[5] = {0.0, 0.3, 0.0, 0.6, 0.6};
  * reference's order and the pixel is written once (12 B of HBM traffic per
  * pixel).  One workgroup = one wavefront = one 8x8 tile.
  */
-template <int LEVELS, bool DOF>
+template <int LEVELS, bool DOF, bool MLC>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const RenderParams P)
 {
     extern __shared__ __align__(16) char lds_all[];
@@ -907,49 +979,19 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     const uint32_t tcol = bcol * kWavesPerBlock + wave;
 
     /* Which nodes can this tile's primary rays reach, and which can occlude its
-     * shadow rays towards light l?  The host supplies one pixel rectangle per node
-     * and the side intervals of every light (RenderParams); lane n tests node n
-     * and a ballot makes the wave-uniform masks — before any lane leaves, so that
-     * every node has its lane. */
-    uint32_t pmask = 0xFFFFFFFFu;
-    uint32_t smask[kMaxCullLights];
-#pragma unroll
-    for (int l = 0; l < kMaxCullLights; ++l) smask[l] = 0xFFFFFFFFu;
+     * shadow rays towards the first light?  Lane n tests node n's rectangle and a
+     * ballot makes the wave-uniform masks — before any lane leaves, so that every
+     * node has its lane. */
+    uint32_t pmask = 0xFFFFFFFFu, smask0 = 0xFFFFFFFFu;
     if constexpr (!DOF) {
         if (P.n_cull) {
-            const int tx0 = (int)(tcol * kTileW), tx1 = tx0 + kTileW;
-            const uint32_t lr_first = trow * kTileH + P.row_offset;
-            uint32_t lr_last = trow * kTileH + kTileH - 1;
-            if (lr_last >= P.local_rows) lr_last = P.local_rows - 1;
-            lr_last += P.row_offset;
-            int ty0 = (int)lr_first, ty1 = (int)lr_last;
-            if (P.strip_world > 1) { /* the strip map is monotonic in the local row */
-                const uint32_t sh = P.strip_height;
-                ty0 = (int)(((lr_first / sh) * P.strip_world + P.strip_rank) * sh + lr_first % sh);
-                ty1 = (int)(((lr_last / sh) * P.strip_world + P.strip_rank) * sh + lr_last % sh);
-            }
-            /* the rectangles live in the kernel-argument segment: a per-lane load from it */
-            typedef const int __attribute__((address_space(4))) *KInt;
-            KInt rects = (KInt)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() +
-                                __builtin_offsetof(RenderParams, cull_rect));
-            const bool mine = (uint32_t)lane < P.n_cull; /* lanes >= n_cull stand for "always test" */
-            const int ln = mine ? lane : 0;
-            const int r0 = rects[4 * ln + 0], r1 = rects[4 * ln + 1], r2 = rects[4 * ln + 2], r3 = rects[4 * ln + 3];
-            const bool seen = !mine || !(r2 <= tx0 || r0 >= tx1 || r3 <= ty0 || r1 > ty1);
-            pmask = (uint32_t)__ballot(seen);
-            /* sample coordinates of this tile: x in [tx0, tx0 + 8.6), y in [ty0, ty1 + 0.6] */
-            const int sx1 = tx1 + 1, sy1 = ty1 + 1;
-#pragma unroll
-            for (int l = 0; l < kMaxCullLights; ++l) {
-                if ((uint32_t)l >= P.n_cull_lights) break;
-                const int *sd = P.light_side[l];
-                const bool in_left = tx0 >= sd[0] && tx0 <= sd[1];   /* light on the ">= tx0" side of the left plane */
-                const bool in_right = sx1 >= sd[2] && sx1 <= sd[3];  /* light on the "<= sx1" side of the right plane */
-                const bool in_top = ty0 >= sd[4] && ty0 <= sd[5];
-                const bool in_bottom = sy1 >= sd[6] && sy1 <= sd[7];
-                const bool culled = mine && ((in_left && r2 <= tx0) || (in_right && r0 >= sx1) || (in_top && r3 <= ty0) || (in_bottom && r1 >= sy1));
-                smask[l] = (uint32_t)__ballot(!culled);
-            }
+            int tx0, ty0, ty1;
+            tile_bounds(P, tx0, ty0, ty1);
+            bool mine;
+            int r0, r1, r2, r3;
+            lane_rect(P, lane, mine, r0, r1, r2, r3);
+            pmask = (uint32_t)__ballot(!mine || !(r2 <= tx0 || r0 >= tx0 + kTileW || r3 <= ty0 || r1 > ty1));
+            smask0 = shadow_cull_mask(P, lane, 0);
         }
     }
 
@@ -972,8 +1014,7 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     cx.lds = lds;
     cx.lane = lane;
     cx.primary_mask = pmask;
-#pragma unroll
-    for (int l = 0; l < kMaxCullLights; ++l) cx.shadow_mask[l] = smask[l];
+    cx.shadow_mask0 = smask0;
     Counters cnt = {0, 0};
     /* prepassOnly (rt/renderer.d:110-130): the pixel shows the sample of the
      * top-left pixel of its 16x16 block inside its bucket */
@@ -993,7 +1034,7 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     F3 accum = mkf(0, 0, 0);
 #pragma unroll 1
     for (uint32_t s = 0; s < ntaps; ++s) {
-        const F3 c = render_sample<LEVELS, DOF>(P, cx, (double)sx + k_aa_x[s], (double)sy + k_aa_y[s], pixel, s, cnt, nullptr);
+        const F3 c = render_sample<LEVELS, DOF, MLC>(P, cx, (double)sx + k_aa_x[s], (double)sy + k_aa_y[s], pixel, s, cnt, nullptr);
         accum = s == 0 ? c : accum + c;
     }
     if (ntaps > 1) accum = accum / (float)ntaps; /* `accum / 5`: Color / float */
@@ -1022,10 +1063,10 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.lds = lds;
     cx.lane = 0;
     cx.primary_mask = 0xFFFFFFFFu;
-    for (int l = 0; l < kMaxCullLights; ++l) cx.shadow_mask[l] = 0xFFFFFFFFu;
+    cx.shadow_mask0 = 0xFFFFFFFFu;
     Counters cnt = {0, 0};
     const uint64_t pixel = (uint64_t)P.probe_y * P.width + (uint64_t)P.probe_x;
-    const F3 c = render_sample<LEVELS, DOF>(P, cx, (double)P.probe_x, (double)P.probe_y, pixel, 0, cnt, P.probe_out);
+    const F3 c = render_sample<LEVELS, DOF, false>(P, cx, (double)P.probe_x, (double)P.probe_y, pixel, 0, cnt, P.probe_out);
     P.probe_out->color[0] = c.r;
     P.probe_out->color[1] = c.g;
     P.probe_out->color[2] = c.b;
@@ -1095,9 +1136,11 @@ int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, vo
     const dim3 grid(p.blocks_x * tiles_y_pad), block(kBlockThreads);
     const size_t lds = (size_t)C2RT_UNIT * kCsgLdsPerLevel * kWavesPerBlock;
     if (dof_or_stereo)
-        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, true>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, true, false>), grid, block, lds, s, p);
+    else if (p.n_cull_lights > 1)
+        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, false, true>), grid, block, lds, s, p);
     else
-        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, false>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, false, false>), grid, block, lds, s, p);
     return (int)hipGetLastError();
 }
 

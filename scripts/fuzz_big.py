@@ -5,8 +5,9 @@ import chess2rt_amd as c2, oracle_lib as orc
 from scene_fuzz import random_scene_sdl
 d='/tmp/fz'; os.makedirs(d, exist_ok=True); shutil.copy(ROOT+'/tests/golden/scenes/floor.bmp', d+'/floor.bmp')
 ctx=c2.Context(0); worst=0; bad=0; nne=0
+from scene_fuzz import many_lights_scene_sdl
 for seed in range(1000, 2500):
-    open(d+'/f.sdl','w').write(random_scene_sdl(seed, max_depth=4 if seed%2 else 3))
+    open(d+"/f.sdl","w").write(many_lights_scene_sdl(seed) if seed % 5 == 0 else random_scene_sdl(seed, max_depth=4 if seed%2 else 3))
     s=c2.parseSceneFromFile(d+'/f.sdl'); s.setFrameSize(64,48); cam=s.beginFrame(); opts=s.renderOpts(count_rays=1)
     ctx.uploadScene(s.desc); a=ctx.renderFrame(cam,opts); pr,sh=ctx.rayStats(); st={}
     r=orc.render_frame(s.desc,cam,opts,8,st)

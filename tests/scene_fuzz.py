@@ -71,3 +71,16 @@ def random_scene_sdl(seed, max_depth=3):
         "  Shaders {\n    " + "\n    ".join(shaders) + "\n  }",
         "  Nodes {\n    " + "\n    ".join(nodes) + "\n  }",
         "}", ""])
+
+
+def many_lights_scene_sdl(seed):
+    """Like random_scene_sdl but with 4-6 lights placed all around (also behind and beside the camera):
+    exercises the per-light shadow-culling thresholds."""
+    r = random.Random(10_000 + seed)
+    text = random_scene_sdl(seed, max_depth=2)
+    lights = []
+    for i in range(r.randint(4, 6)):
+        lights.append('PointLight "m%d" { pos %s; color %s; power %.6g }' % (i, _v(r, -250, 250), _v(r, 0.2, 1), r.uniform(5000, 40000)))
+    head, rest = text.split("  Lights {\n", 1)
+    _, tail = rest.split("\n  }\n", 1)
+    return head + "  Lights {\n    " + "\n    ".join(lights) + "\n  }\n" + tail

@@ -395,6 +395,25 @@ def test_random_scene_fuzz(gpu_ctx, tmp_path, scenes_dir):
             assert md <= TOL and nbad == 0, (seed, md)
             assert (pr, sh) == (st["primary"], st["shadow"]), seed
     print("fuzz: worst max|d| over 120 scenes = %.3g" % worst)
+    # 4-6 lights all around the scene, incl. behind the camera: per-light shadow culling
+    from scene_fuzz import many_lights_scene_sdl
+
+    for seed in range(40):
+        path = tmp_path / ("lights%d.sdl" % seed)
+        path.write_text(many_lights_scene_sdl(seed))
+        scene = c2.parseSceneFromFile(str(path))
+        if seed % 2:
+            scene.setFrameSize(133, 75)
+        cam = scene.beginFrame()
+        opts = scene.renderOpts(count_rays=1)
+        gpu_ctx.uploadScene(scene.desc)
+        a = gpu_ctx.renderFrame(cam, opts)
+        pr, sh = gpu_ctx.rayStats()
+        st = {}
+        ref = orc.render_frame(scene.desc, cam, opts, 2, st)
+        assert np.array_equal(np.isnan(a), np.isnan(ref)), seed
+        assert maxdiff(a, ref)[0] <= TOL, seed
+        assert (pr, sh) == (st["primary"], st["shadow"]), seed
 
 
 def test_prepass_only_preview(gpu_ctx, tmp_path):
