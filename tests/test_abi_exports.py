@@ -109,3 +109,26 @@ def test_local_rows_is_pure_host_arithmetic():
             assert n == local_rows(h, sh, r, world)
             total += n
         assert total == h
+
+
+def _build_c_program(src, exe, with_oracle=False):
+    cmd = ["gcc", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", os.path.join(ROOT, "chess2rt_amd"), "-lc2rt",
+           "-Wl,-rpath," + os.path.join(ROOT, "chess2rt_amd")]
+    if with_oracle:
+        cmd += ["-L", os.path.join(ROOT, "oracle"), "-lc2rt_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
+    subprocess.check_call(cmd + ["-lm", "-o", exe])
+
+
+def test_plain_c_caller_links_and_fails_loudly_without_gpu(tmp_path):
+    """The boundary is usable from plain C (no C++ or torch types leak into the
+    header), and with no GPU the caller gets C2RT_ERR_NO_DEVICE, not a CPU frame."""
+    import torch
+
+    exe = str(tmp_path / "c_abi_demo")
+    _build_c_program(os.path.join(ROOT, "examples", "c_abi_demo.c"), exe)
+    p = subprocess.run([exe, "32", "24"], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert p.returncode == 0, p.stderr
+        assert "primary" in p.stdout
+    else:
+        assert p.returncode != 0 and "no usable GPU" in p.stderr

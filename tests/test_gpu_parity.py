@@ -510,3 +510,17 @@ def test_rgb32_frame_and_strips(gpu_ctx):
     gpu_ctx.deinterleaveStripsRGB32(gathered.data_ptr(), frame.data_ptr(), W, H, 8, world, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(frame.cpu().numpy().astype(np.uint32), packed)
+
+
+def test_plain_c_caller_matches_oracle(tmp_path):
+    """examples/c_abi_demo.c's hand-built tables (CsgDiff, Phong, checker) through
+    the C ABI from a C program, against the oracle linked into the same program."""
+    import subprocess
+
+    from test_abi_exports import ROOT, _build_c_program
+
+    exe = str(tmp_path / "c_abi_check")
+    _build_c_program(os.path.join(ROOT, "tests", "c_abi_check.c"), exe, with_oracle=True)
+    p = subprocess.run([exe, "200", "152"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "beyond_tol 0" in p.stdout
