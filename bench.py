@@ -46,6 +46,7 @@ WORKLOADS = {
     "csg_stress_4k_4spp": ("csg_stress.sdl", 3840, 2160, 4, False),
 }
 
+VALU_PEAK_TSLOTS = 256 * 4 * 16 * 2.4e9 / 1e12  # CUs x SIMDs x lanes/clk x clock (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -327,11 +328,13 @@ def main():
         tex_bytes = int(scene.desc.contents.n_texels) * 12
         alg_bytes = pipe.my_rows * r["width"] * 12 + tex_bytes
         achieved = alg_bytes / (r["kernel_ms"] * 1e-3) / 1e9
-        traffic = None
+        traffic = valu_insts = None
         prof = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if world == 1 and os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                prof_data = json.load(open(prof))
+                traffic = prof_data.get("hbm_bytes_per_launch")
+                valu_insts = prof_data.get("valu_insts_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -374,6 +377,12 @@ def main():
                 "note": "by the numbers this path is fp64-VALU bound, not HBM bound (DESIGN.md 4.1): 12 B/pixel is all it must move",
             },
         }
+        if valu_insts:
+            # what actually bounds this kernel: VALU issue slots (fp64 runs at the full 16 lanes/clk/SIMD rate).
+            # Instruction count from the committed PMC pass, duration measured live.
+            slots = valu_insts * 64 / (r["kernel_ms"] * 1e-3) / 1e12
+            out["roofline"]["valu"] = {"achieved": slots, "peak": VALU_PEAK_TSLOTS, "unit": "T lane-slots/s", "frac": slots / VALU_PEAK_TSLOTS,
+                                       "insts_per_launch": valu_insts, "source": "SQ_INSTS_VALU, profiles/traffic_%s.json" % args.workload}
         if world == 1 and not args.no_cpu_baseline:
             full = scene.renderOpts(taps=r["taps"])
             out["cpu_baseline"] = cpu_baseline(scene, r["cam"], full, rays_per_frame)
