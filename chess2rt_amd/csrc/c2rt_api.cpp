@@ -575,6 +575,25 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         for (int i = 0; i < 9; ++i) ident = ident && d.m[i] == I[i] && d.inv[i] == I[i] && d.tinv[i] == I[i];
         if (ident) d.flags |= kNodeIdentityMatrix;
         if (d.off[0] == 0 && d.off[1] == 0 && d.off[2] == 0) d.flags |= kNodeZeroOffset;
+        /* shading inputs of this node in one record */
+        const DevShader &sh = shaders[d.shader];
+        DevMat &m = d.mat;
+        m.shader_type = sh.type;
+        m.tex = sh.tex;
+        m.tex_type = sh.tex >= 0 ? textures[sh.tex].type : -1;
+        m.strength = sh.strength;
+        std::memcpy(m.color, sh.color, sizeof m.color);
+        m.exponent = sh.exponent;
+        if (m.tex_type == C2RT_TEX_CHECKER) {
+            std::memcpy(m.texdata, textures[sh.tex].color, 6 * sizeof(float));
+            std::memcpy(m.texdata + 6, &textures[sh.tex].param[0], sizeof(double));
+        } else if (m.tex_type == C2RT_TEX_BITMAP) {
+            const DevTex &t = textures[sh.tex];
+            m.texdata[0] = t.width;
+            m.texdata[1] = t.height;
+            std::memcpy(m.texdata + 2, &t.scaling, sizeof(float));
+            std::memcpy(m.texdata + 4, &t.offset, sizeof(uint64_t));
+        }
     }
 
     /* world-space bounding boxes of the nodes: object-space bounding sphere -> its

@@ -66,7 +66,24 @@ enum NodeFlags : uint32_t {
     kNodeZeroOffset = 2u,          /* offset == 0: skip the subtraction/addition */
 };
 
-struct alignas(16) DevNode {       /* 336 B; the first 112 B are all a primitive under an identity matrix needs */
+/* What shading a hit on a node reads, flattened at upload from
+ * shaders[node.shader] and textures[shader.tex]: one scalar load per distinct
+ * closest node of a wave instead of a node -> shader -> texture chain of
+ * per-lane loads (each link a full memory round trip). */
+struct alignas(16) DevMat {        /* 80 B */
+    int32_t shader_type;
+    int32_t tex_type;              /* -1: untextured */
+    int32_t tex;                   /* texture index (Procedure2 reads its tables from there) */
+    float strength;
+    float color[3];
+    uint32_t pad;
+    double exponent;
+    uint32_t pad2[2];
+    /* checker: color1.rgb, color2.rgb, size (double)  |  bitmap: width, height, scaling, -, offset (u64) */
+    uint32_t texdata[8];
+};
+
+struct alignas(16) DevNode {       /* 416 B; the first 112 B are all a primitive under an identity matrix needs */
     int32_t geom, shader;
     uint32_t flags, pad;
     double off[3];
@@ -76,6 +93,7 @@ struct alignas(16) DevNode {       /* 336 B; the first 112 B are all a primitive
     double m[9];                   /* transform */
     double tinv[9];                /* transposedInverse */
     double pad3;
+    DevMat mat;
 };
 
 struct alignas(16) DevShader {     /* 32 B */

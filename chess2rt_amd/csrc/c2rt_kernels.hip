@@ -725,17 +725,56 @@ DEV F3 bitmap_filtered(const float4 *texels, uint32_t width, uint32_t height, fl
            mkf(c11.x, c11.y, c11.z) * w11;
 }
 
-DEV F3 tex_color(const RenderParams &P, int tex, double u, double v)
+/* A node's shading inputs in registers (DevMat, c2rt_device.h). */
+struct Mat {
+    int shader_type, tex_type, tex;
+    float strength;
+    F3 color;
+    double exponent;
+    uint32_t td[8];
+};
+
+/* One scalar record load per DISTINCT closest node of the wave (usually one or
+ * two) instead of a node -> shader -> texture chain of per-lane loads. */
+DEV void load_mat(const DevNode *nodes, int closest, Mat &m)
 {
-    const DevTex *T = P.textures + tex;
-    const int type = T->type;
+    m.shader_type = m.tex = 0;
+    m.tex_type = -1;
+    m.strength = 0;
+    m.color = mkf(0, 0, 0);
+    m.exponent = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m.td[i] = 0;
+    bool todo = closest >= 0;
+    while (todo) {
+        const int u = __builtin_amdgcn_readfirstlane(closest);
+        if (closest == u) {
+            const DevMat *M = &nodes[u].mat; /* wave-uniform address: scalar loads */
+            m.shader_type = M->shader_type;
+            m.tex_type = M->tex_type;
+            m.tex = M->tex;
+            m.strength = M->strength;
+            m.color = ldf3(M->color);
+            m.exponent = M->exponent;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m.td[i] = M->texdata[i];
+            todo = false;
+        }
+    }
+}
+
+DEV F3 tex_color(const RenderParams &P, const Mat &m, double u, double v)
+{
+    const int type = m.tex_type;
     if (type == C2RT_TEX_CHECKER) { /* Checker.getTexColor — rt/texture.d:36-54 */
-        const double size = T->param[0];
+        const double size = __hiloint2double((int)m.td[7], (int)m.td[6]);
         const int x = d2i_x86(floor(u / size));
         const int y = d2i_x86(floor(v / size));
         const int white = (int)((uint32_t)x + (uint32_t)y) % 2;
-        return white ? ldf3(T->color + 3) : ldf3(T->color);
+        return white ? mkf(__uint_as_float(m.td[3]), __uint_as_float(m.td[4]), __uint_as_float(m.td[5]))
+                     : mkf(__uint_as_float(m.td[0]), __uint_as_float(m.td[1]), __uint_as_float(m.td[2]));
     } else if (type == C2RT_TEX_PROCEDURE2) { /* Procedure2.getTexColor — rt/texture.d:77-86 */
+        const DevTex *T = P.textures + m.tex;
         F3 result = mkf(0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -743,15 +782,16 @@ DEV F3 tex_color(const RenderParams &P, int tex, double u, double v)
                                ldf3(T->color + 9 + 3 * i) * (float)c2_sin(v * T->param[3 + i]));
         return result;
     } else { /* BitmapTexture.getTexColor — rt/texture.d:116-126 */
-        const double s = (double)T->scaling;
+        const double s = (double)__uint_as_float(m.td[2]);
         u *= s;
         v *= s;
         u = u - floor(u);
         v = v - floor(v);
-        const uint32_t w = T->width, hgt = T->height;
+        const uint32_t w = m.td[0], hgt = m.td[1];
         const float tx = (float)u * (float)w;
         const float ty = (float)v * (float)hgt;
-        return bitmap_filtered(reinterpret_cast<const float4 *>(P.texels) + T->offset, w, hgt, tx, ty);
+        const uint64_t offset = (uint64_t)m.td[4] | ((uint64_t)m.td[5] << 32);
+        return bitmap_filtered(reinterpret_cast<const float4 *>(P.texels) + offset, w, hgt, tx, ty);
     }
 }
 
@@ -763,13 +803,11 @@ DEV F3 tex_color(const RenderParams &P, int tex, double u, double v)
  * culling mask of lights 1.. (per sample); single-light scenes run the instance
  * without that code. */
 template <int LEVELS, bool MLC>
-DEV F3 shade(const RenderParams &P, const Ctx &cx, int shader, D3 rd, const Hit &h, uint32_t &shadow_rays)
+DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const Hit &h, uint32_t &shadow_rays)
 {
-    const DevShader *S = P.shaders + shader;
-    const bool phong = S->type == C2RT_SHADER_PHONG;
+    const bool phong = mat.shader_type == C2RT_SHADER_PHONG;
     const D3 N = dot(rd, h.n) < 0 ? h.n : -h.n; /* faceforward — rt/imported_types.d:69-73 */
-    const int tex = S->tex;
-    const F3 diffuse = tex >= 0 ? tex_color(P, tex, h.u, h.v) : ldf3(S->color);
+    const F3 diffuse = mat.tex_type >= 0 ? tex_color(P, mat, h.u, h.v) : mat.color;
     F3 lightContrib = mkf(P.ambient[0], P.ambient[1], P.ambient[2]);
     F3 specular = mkf(0, 0, 0);
     const uint32_t nl = P.n_lights;
@@ -791,7 +829,7 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, int shader, D3 rd, const Hit 
                     const D3 R = normalized(ml - N * (2 * dot(ml, N)));
                     const double cosGamma = dot(R, -rd);
                     if (cosGamma > 0)
-                        avgSpecular = avgSpecular + baseLight * (float)c2_pow(cosGamma, S->exponent) * S->strength;
+                        avgSpecular = avgSpecular + baseLight * (float)c2_pow(cosGamma, mat.exponent) * mat.strength;
                 }
             }
         }
@@ -874,7 +912,9 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt,
         if (node_intersect<LEVELS, kFull>(cx, P.nodes + n, ray, best)) closest = (int)n;
     }
     /* Sphere u,v are read only by textured shaders (and the probe) */
-    if (closest >= 0 && best.uv_pending && (probe || P.shaders[P.nodes[closest].shader].tex >= 0)) finish_uv(best);
+    Mat mat;
+    load_mat(P.nodes, closest, mat);
+    if (closest >= 0 && best.uv_pending && (probe || mat.tex_type >= 0)) finish_uv(best);
     if (probe) {
         probe->closest_node = closest;
         probe->leaf_geom = closest >= 0 ? best.g : -1;
@@ -885,7 +925,7 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt,
         probe->ray_dir[0] = d.x; probe->ray_dir[1] = d.y; probe->ray_dir[2] = d.z;
     }
     if (closest < 0) return mkf(0, 0, 0); /* Environment.getEnvironment — rt/environment.d:7-10 */
-    return shade<LEVELS, MLC>(P, cx, P.nodes[closest].shader, d, best, cnt.shadow);
+    return shade<LEVELS, MLC>(P, cx, mat, d, best, cnt.shadow);
 }
 
 /* adjustSaturation + combineStereo — rt/color.d:10-15,77-83 */
