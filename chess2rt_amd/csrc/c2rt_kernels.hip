@@ -952,37 +952,33 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
         screen_ray<false>(P, x, y, 0, rng, o, d);
         return raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
     } else {
+        /* renderSampleDof / renderSampleStereo / renderSampleDefault (rt/renderer.d:270-313)
+         * as ONE loop around ONE trace call site (five inlined copies of the tracer made
+         * this instance five times the size of the others): lens samples x eyes, in the
+         * reference's order, with the random draws in its order. */
         const bool stereo = P.cam.stereo_separation != 0;
-        if (P.cam.dof) {
-            F3 average = mkf(0, 0, 0);
-            const uint32_t ns = P.cam.num_samples;
-            for (uint32_t i = 0; i < ns; ++i) {
-                rng.sample = i;
-                rng.dim = 0;
-                double jx = rng_next(rng), jy = rng_next(rng);
-                if (!stereo) {
-                    screen_ray<true>(P, x + jx * 1, y + jy * 1, 0, rng, o, d);
-                    average = average + raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
-                } else {
-                    screen_ray<true>(P, x + jx * 1, y + jy * 1, -1, rng, o, d);
-                    const F3 l = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
-                    jx = rng_next(rng), jy = rng_next(rng);
-                    screen_ray<true>(P, x + jx * 1, y + jy * 1, +1, rng, o, d);
-                    const F3 r = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, nullptr);
-                    average = average + combine_stereo(l, r);
+        const bool dof = P.cam.dof != 0;
+        const uint32_t ns = dof ? P.cam.num_samples : 1u;
+        const int eyes = stereo ? 2 : 1;
+        F3 average = mkf(0, 0, 0), sample = mkf(0, 0, 0);
+        for (uint32_t i = 0; i < ns; ++i) {
+            rng.sample = i;
+            rng.dim = 0;
+            for (int e = 0; e < eyes; ++e) {
+                double sx = x, sy = y;
+                if (dof) {
+                    const double jx = rng_next(rng), jy = rng_next(rng);
+                    sx = x + jx * 1;
+                    sy = y + jy * 1;
                 }
+                screen_ray<true>(P, sx, sy, stereo ? (e == 0 ? -1 : +1) : 0, rng, o, d);
+                const F3 c = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, e == 0 ? probe : nullptr);
+                sample = e == 0 ? c : combine_stereo(sample, c);
             }
-            return average / (float)ns;
+            if (!dof) return sample;
+            average = average + sample;
         }
-        if (!stereo) {
-            screen_ray<true>(P, x, y, 0, rng, o, d);
-            return raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
-        }
-        screen_ray<true>(P, x, y, -1, rng, o, d);
-        const F3 l = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
-        screen_ray<true>(P, x, y, +1, rng, o, d);
-        const F3 r = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, nullptr);
-        return combine_stereo(l, r);
+        return average / (float)ns;
     }
 }
 
