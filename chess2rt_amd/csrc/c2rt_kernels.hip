@@ -56,6 +56,11 @@ __device__ __noinline__ double c2_cos(double a) { return cos(a); }
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
 #endif
+#ifndef C2RT_OCC_DOF
+/* measured: the CSG-free DOF instance is faster at 4 waves/SIMD with 19 spilled
+ * VGPRs (zaphod 4K x25: 6.83 ms) than at 3 without spills (7.05 ms) */
+#define C2RT_OCC_DOF C2RT_OCC
+#endif
 #ifndef C2RT_XCD_SWIZZLE
 #define C2RT_XCD_SWIZZLE 1
 #endif
@@ -993,7 +998,7 @@ __constant__ double k_aa_y[5] = {0.0, 0.3, 0.0, 0.6, 0.6};
  * pixel).  One workgroup = one wavefront = one 8x8 tile.
  */
 template <int LEVELS, bool DOF, bool MLC>
-__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const RenderParams P)
+DEV void render_body(const RenderParams &P)
 {
     extern __shared__ __align__(16) char lds_all[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -1086,6 +1091,20 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
     }
 }
 
+template <int LEVELS, bool DOF, bool MLC>
+__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const RenderParams P)
+{
+    render_body<LEVELS, DOF, MLC>(P);
+}
+
+/* The depth-of-field / stereo instance carries the lens sampling state on top of
+ * the tracer's and has its own register budget (C2RT_OCC_DOF). */
+template <int LEVELS>
+__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_DOF render_kernel_dof(const RenderParams P)
+{
+    render_body<LEVELS, true, false>(P);
+}
+
 /* renderPixel — rt/renderer.d:46-57: one lane, one sample, full trace result */
 template <int LEVELS, bool DOF>
 __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
@@ -1172,7 +1191,7 @@ int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, vo
     const dim3 grid(p.blocks_x * tiles_y_pad), block(kBlockThreads);
     const size_t lds = (size_t)C2RT_UNIT * kCsgLdsPerLevel * kWavesPerBlock;
     if (dof_or_stereo)
-        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, true, false>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT>), grid, block, lds, s, p);
     else if (p.n_cull_lights > 1)
         hipLaunchKernelGGL((render_kernel<C2RT_UNIT, false, true>), grid, block, lds, s, p);
     else
