@@ -11,7 +11,8 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -fhip-fp32-
               -Wall -Wno-unused-function $(EXTRA_HIPFLAGS)
 CXXFLAGS   := -O2 -std=c++17 -fPIC $(FPFLAGS) -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 CSRC       := chess2rt_amd/csrc
-# development knob: `make VARIANT=name EXTRA_HIPFLAGS=...` builds chess2rt_amd/libc2rt_name.so
+# development knob: `make VARIANT=name EXTRA_HIPFLAGS=... EXTRA_KERNEL_FLAGS=...` builds chess2rt_amd/libc2rt_name.so
+# (EXTRA_KERNEL_FLAGS reach only the hipcc kernel units, e.g. -mllvm options)
 VARIANT    ?=
 BUILD      := build$(if $(VARIANT),_$(VARIANT))
 LIBNAME    := chess2rt_amd/libc2rt$(if $(VARIANT),_$(VARIANT)).so
@@ -26,7 +27,7 @@ $(BUILD):
 	mkdir -p $(BUILD)
 
 $(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -DC2RT_UNIT=$* -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$* -c $< -o $@
 
 $(BUILD)/c2rt_api.o: $(CSRC)/c2rt_api.cpp $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
 	g++ $(CXXFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
