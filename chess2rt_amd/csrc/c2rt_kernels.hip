@@ -576,6 +576,17 @@ DEV RayW make_ray(D3 o, D3 d)
     return r;
 }
 
+/* The first node >= n that a culling mask keeps: bit k of `mask` clear means
+ * node k (< kMaxCullNodes = 32) cannot be reached; nodes beyond the mask are
+ * always visited.  Wave-uniform: a shift and a find-first-set on the scalar unit. */
+DEV uint32_t next_node(uint32_t mask, uint32_t n)
+{
+    static_assert(kMaxCullNodes == 32, "one 32-bit mask");
+    if (n >= 32u) return n;
+    const uint32_t m = mask >> n;
+    return m ? n + (uint32_t)__builtin_ctz(m) : 32u;
+}
+
 /* Node.intersect; `best.dist` is data.dist (world units) in and out. */
 template <int LEVELS, int NEED>
 DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &best)
@@ -701,10 +712,8 @@ DEV bool test_visibility(const Ctx &cx, D3 from, D3 to, uint32_t node_mask)
     Hit temp;
     temp.dist = mag(to - from);
     const uint32_t nn = cx.n_nodes;
-    for (uint32_t n = 0; n < nn; ++n) {
-        if (n < (uint32_t)kMaxCullNodes && !((node_mask >> n) & 1u)) continue; /* scalar branch */
+    for (uint32_t n = next_node(node_mask, 0); n < nn; n = next_node(node_mask, n + 1)) /* scalar loop, file order */
         if (node_intersect<LEVELS, kBool>(cx, cx.nodes + n, ray, temp)) return false;
-    }
     return true;
 }
 
@@ -912,10 +921,8 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt,
     best.axis_n = false;
     int closest = -1;
     const uint32_t nn = P.n_nodes;
-    for (uint32_t n = 0; n < nn; ++n) {
-        if (n < (uint32_t)kMaxCullNodes && !((cx.primary_mask >> n) & 1u)) continue; /* scalar branch */
+    for (uint32_t n = next_node(cx.primary_mask, 0); n < nn; n = next_node(cx.primary_mask, n + 1)) /* scalar loop, file order */
         if (node_intersect<LEVELS, kFull>(cx, P.nodes + n, ray, best)) closest = (int)n;
-    }
     /* Sphere u,v are read only by textured shaders (and the probe) */
     Mat mat;
     load_mat(P.nodes, closest, mat);
