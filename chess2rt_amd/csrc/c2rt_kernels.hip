@@ -174,11 +174,11 @@ DEV bool plane_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h, bool 
 {
     const D3 o = r.o, d = r.d;
     const double y = G->p[0], limit = G->p[1];
-    if ((o.y > y && d.y > -1e-9) || (o.y < y && d.y < 1e-9)) return false;
+    /* (bitwise forms of the reference's conditions: same truth table incl. NaN, one branch each) */
+    if (((o.y > y) & (d.y > -1e-9)) | ((o.y < y) & (d.y < 1e-9))) return false;
     const double mult = (o.y - y) / -d.y;
-    if (mult > h.dist) return false;
     const D3 p = o + d * mult;
-    if (fabs(p.x) > limit || fabs(p.z) > limit) return false;
+    if ((mult > h.dist) | (fabs(p.x) > limit) | (fabs(p.z) > limit)) return false;
     h.dist = mult;
     if (NEED >= kPoint) { h.p = p; h.g = gid; }
     if (C2RT_WANT_FULL(NEED, full)) { h.n = mk(0, 1, 0); h.u = p.x; h.v = p.z; h.uv_pending = false; h.axis_n = true; }
@@ -198,19 +198,17 @@ DEV bool sphere_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h, bool
     const double C = sqmag(H) - R * R;
     const double BB = B * B;
     const double Dscr = BB - 4 * A * C;
-    if (Dscr < 0) return false;
-    /* Outside the sphere and moving away: sqrt(Dscr) < B by a margin far above
-     * rounding, so both roots are negative — the reference returns false after
-     * a sqrt and two divisions; skip them.  (Near-degenerate cases fall through
-     * to the literal evaluation.) */
-    if (C > 0 && B > 0 && Dscr < BB * (1 - 1e-8)) return false;
+    /* Dscr < 0: no real root.  Or: outside the sphere and moving away — sqrt(Dscr) < B
+     * by a margin far above rounding, so both roots are negative: the reference
+     * returns false after a sqrt and two divisions; skip them.  (Near-degenerate
+     * cases fall through to the literal evaluation.)  One branch for both. */
+    if ((Dscr < 0) | ((C > 0) & (B > 0) & (Dscr < BB * (1 - 1e-8)))) return false;
     const double sq = sqrt(Dscr);
     const double A2 = 2 * A;
     /* x1 = (-B + sq) / (2A) is only read when x2 < 0 */
     double sol = (-B - sq) / A2;
     if (sol < 0) sol = (-B + sq) / A2;
-    if (sol < 0) return false;
-    if (sol > h.dist) return false;
+    if ((sol < 0) | (sol > h.dist)) return false;
     h.dist = sol;
     if (NEED >= kPoint) {
         const D3 p = o + d * sol;
@@ -242,16 +240,18 @@ DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, doubl
     if (fabs(dy) < 1e-9) return false;
     bool found = false;
     const double den = -dy;
+    const double xlo = cx - halfSide, xhi = cx + halfSide, zlo = cz - halfSide, zhi = cz + halfSide;
 #pragma unroll
     for (int side = -1; side <= 1; side += 2) {
         const double num = oy - (cy + side * halfSide);
-        const bool negative = (num < 0) ? (den > 0) : (num > 0 && den < 0);
+        const bool negative = ((num < 0) & (den > 0)) | ((num > 0) & (den < 0));
         if (negative) continue;          /* mult < 0 */
         const double mult = num / den;
-        if (mult < 0) continue;          /* kept for NaN / zero corner cases */
-        if (mult > h.dist) continue;
         const double px = ox + dx * mult, pz = oz + dz * mult;
-        if (px < cx - halfSide || px > cx + halfSide || pz < cz - halfSide || pz > cz + halfSide) continue;
+        /* the reference's four rejections (mult < 0 kept for NaN / zero corner cases) as ONE
+         * predicate: one divergent branch per face instead of four */
+        const bool reject = (mult < 0) | (mult > h.dist) | (px < xlo) | (px > xhi) | (pz < zlo) | (pz > zhi);
+        if (reject) continue;
         h.dist = mult;
         if (NEED >= kPoint) h.p = o + d * mult;
         if (C2RT_WANT_FULL(NEED, full)) {
@@ -296,7 +296,7 @@ DEV bool misses_bound(const DevGeom *G, const ORay &r)
     const D3 H = r.o - ld3(G->bound);
     const double b = dot(H, r.d);
     const double c = sqmag(H) - G->bound[3];
-    return c > 0 && (b > 0 || b * b < c);
+    return (c > 0) & ((b > 0) | (b * b < c));
 }
 
 /* isInside — rt/geometry.d:25-28,127-130,165-170,334-337 */
