@@ -8,7 +8,7 @@ CC         ?= gcc
 ARCH       ?= gfx950
 FPFLAGS    := -ffp-contract=off -fno-fast-math
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt \
-              -Wall -Wno-unused-function $(EXTRA_HIPFLAGS)
+              -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical $(EXTRA_HIPFLAGS)
 CXXFLAGS   := -O2 -std=c++17 -fPIC $(FPFLAGS) -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 CSRC       := chess2rt_amd/csrc
 # development knob: `make VARIANT=name EXTRA_HIPFLAGS=... EXTRA_KERNEL_FLAGS=...` builds chess2rt_amd/libc2rt_name.so

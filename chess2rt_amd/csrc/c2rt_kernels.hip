@@ -309,14 +309,14 @@ DEV bool geom_is_inside(const Ctx &cx, int gid, D3 p)
         return sqmag(ld3(G->p) - p) < G->p[3] * G->p[3];
     } else if (type == C2RT_GEOM_CUBE) {
         const double hs = G->p[3] * 0.5;
-        return fabs(p.x - G->p[0]) <= hs && fabs(p.y - G->p[1]) <= hs && fabs(p.z - G->p[2]) <= hs;
+        return (fabs(p.x - G->p[0]) <= hs) & (fabs(p.y - G->p[1]) <= hs) & (fabs(p.z - G->p[2]) <= hs);
     } else if (type == C2RT_GEOM_PLANE) {
         return false;
     } else {
         if constexpr (LEVEL > 0) {
             const bool a = geom_is_inside<LEVEL - 1>(cx, G->left, p);
             const bool b = geom_is_inside<LEVEL - 1>(cx, G->right, p);
-            return type == C2RT_GEOM_CSG_UNION ? (a || b) : (type == C2RT_GEOM_CSG_INTER ? (a && b) : (a && !b));
+            return type == C2RT_GEOM_CSG_UNION ? (a | b) : (type == C2RT_GEOM_CSG_INTER ? (a & b) : (a & !b));
         } else {
             return false;
         }
@@ -387,8 +387,7 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
         if (side == 0) nL = k;
         n += k;
         /* exact shortcuts (GeomFlags): nothing can switch the operator on */
-        if (side == 0 && k == 0 && (flags & kCsgShortA)) return false;
-        if (side == 1 && k == 0 && (flags & kCsgShortB)) return false;
+        if (k == 0 && (flags & (side ? kCsgShortB : kCsgShortA))) return false;
         if (side == 0) continue;
 
         /* both lists are in: sort — util/array.d:95-111 (index rewound by the inner while) */
@@ -410,9 +409,11 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
         int win = -1;
         for (int i = 0; i < n; ++i) {
             const uint32_t tag = ltag[i * kWave];
-            if ((int)(tag >> 8) == left) inL = !inL; else inR = !inR;
-            const bool in = type == C2RT_GEOM_CSG_UNION ? (inL || inR)
-                          : (type == C2RT_GEOM_CSG_INTER ? (inL && inR) : (inL && !inR));
+            const bool isL = (int)(tag >> 8) == left;
+            inL ^= isL;
+            inR ^= !isL;
+            const bool in = type == C2RT_GEOM_CSG_UNION ? (inL | inR)
+                          : (type == C2RT_GEOM_CSG_INTER ? (inL & inR) : (inL & !inR));
             if (in) { win = i; break; }
         }
         if (win < 0) return false;
@@ -467,8 +468,7 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
         if (side == 0) nL = k; else nR = k;
         n += k;
         /* exact shortcuts (GeomFlags): nothing can switch the operator on */
-        if (side == 0 && k == 0 && (flags & kCsgShortA)) return false;
-        if (side == 1 && k == 0 && (flags & kCsgShortB)) return false;
+        if (k == 0 && (flags & (side ? kCsgShortB : kCsgShortA))) return false;
     }
 
     /* sort — util/array.d:95-111 (index rewound by the inner while) */
@@ -491,9 +491,11 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
     int win = -1;
     for (int i = 0; i < n; ++i) {
         const uint32_t tag = ltag[i * kWave];
-        if ((int)(tag >> 8) == left) inL = !inL; else inR = !inR;
-        const bool in = type == C2RT_GEOM_CSG_UNION ? (inL || inR)
-                      : (type == C2RT_GEOM_CSG_INTER ? (inL && inR) : (inL && !inR));
+        const bool isL = (int)(tag >> 8) == left;
+        inL ^= isL;
+        inR ^= !isL;
+        const bool in = type == C2RT_GEOM_CSG_UNION ? (inL | inR)
+                      : (type == C2RT_GEOM_CSG_INTER ? (inL & inR) : (inL & !inR));
         if (in) { win = i; break; }
     }
     if (win < 0) return false;
@@ -725,7 +727,7 @@ DEV bool test_visibility(const Ctx &cx, D3 from, D3 to, uint32_t node_mask)
 DEV F3 bitmap_filtered(const float4 *texels, uint32_t width, uint32_t height, float x, float y)
 {
     /* isInvalidPos(cast(size_t)x, cast(size_t)y): x, y are >= 0 or NaN here */
-    if (!(x < (float)width) || !(y < (float)height) || width == 0 || height == 0)
+    if (!(x < (float)width) | !(y < (float)height) | (width == 0) | (height == 0))
         return mkf(1.0f, 0.0f, 0.0f); /* NamedColors.red */
     const float fx = floorf(x), fy = floorf(y);
     const uint32_t tx = (uint32_t)fx, ty = (uint32_t)fy;
