@@ -46,6 +46,7 @@ struct c2rt_ctx {
 
     /* world-space corners of every node's padded bounding box (for the per-frame
      * screen rectangles); node_boxed[n] = 0: unbounded, never culled */
+    uint32_t planes_only = 0;          /* every node is an axis plane (kNodeAxisPlane) */
     std::vector<double> node_box;  /* [n_nodes][8][3] */
     std::vector<double> light_pos; /* [n_lights][3] host copy for the per-frame shadow-cull thresholds */
     std::vector<uint8_t> node_boxed;
@@ -262,6 +263,7 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
     p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
     p.blocks_x = (p.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     p.seed = o->seed;
+    p.planes_only = ctx->planes_only;
     p.n_cull = 0;
     if (!cam->dof && cam->stereo_separation == 0 && !o->prepass_bucket) {
         /* up to the last bounded node; nothing bounded => no per-wave work at all */
@@ -594,6 +596,21 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
             std::memcpy(m.texdata + 2, &t.scaling, sizeof(float));
             std::memcpy(m.texdata + 4, &t.offset, sizeof(uint64_t));
         }
+    }
+
+    ctx->planes_only = s->n_nodes > 0;
+    for (uint32_t n = 0; n < s->n_nodes; ++n) {
+        DevNode &d = nodes[n];
+        bool axis = d.g.type == C2RT_GEOM_PLANE;
+        if (axis && !(d.flags & kNodeIdentityMatrix)) {
+            for (int i = 0; i < 9; ++i) {
+                const double a = std::fabs(d.inv[i]);
+                axis = axis && (i % 4 == 0 ? (a >= 1e-100 && a <= 1e100) : d.inv[i] == 0.0);
+            }
+            axis = axis && d.inv[4] > 0;
+        }
+        if (axis) d.flags |= kNodeAxisPlane;
+        else ctx->planes_only = 0;
     }
 
     /* world-space bounding boxes of the nodes: object-space bounding sphere -> its

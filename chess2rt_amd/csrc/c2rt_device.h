@@ -64,6 +64,10 @@ struct alignas(16) DevGeom {       /* 80 B */
 enum NodeFlags : uint32_t {
     kNodeIdentityMatrix = 1u,      /* transform == inverse == I: skip the 3x3 products (exact) */
     kNodeZeroOffset = 2u,          /* offset == 0: skip the subtraction/addition */
+    /* a Plane whose inverse matrix is the identity, or diagonal with finite entries of magnitude in
+     * [1e-100, 1e100] and a positive y entry: the sign of the node-space direction's y follows from
+     * the world-space direction's (plane_points_away, c2rt_kernels.hip) */
+    kNodeAxisPlane = 4u,
 };
 
 /* What shading a hit on a node reads, flattened at upload from
@@ -156,6 +160,9 @@ struct RenderParams {
      * [0..1] ">= x" lo,hi  [2..3] "<= x" lo,hi  [4..5] ">= y"  [6..7] "<= y". */
     uint32_t n_cull_lights;
     int32_t light_side[kMaxCullLights][8];
+    /* every node is an "axis plane" (kNodeAxisPlane): the launcher picks the kernel instance that
+     * decides plane misses from the un-normalised ray direction (plane_points_away) */
+    uint32_t planes_only;
     uint32_t tiles_x, tiles_y;     /* tile grid over the LOCAL rows */
     uint32_t blocks_x;             /* ceil(tiles_x / kWavesPerBlock) */
     uint64_t seed;

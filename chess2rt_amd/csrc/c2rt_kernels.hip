@@ -589,6 +589,42 @@ DEV uint32_t next_node(uint32_t mask, uint32_t n)
     return m ? n + (uint32_t)__builtin_ctz(m) : 32u;
 }
 
+/*
+ * Plane.intersect's first rejection (rt/geometry.d:33-34: origin above the plane
+ * and direction not pointing down, or the mirror image), decided from the
+ * UN-normalised direction `raw` of a ray that would be traced as
+ * make_ray(from, normalized(raw)) against an "axis plane" node (kNodeAxisPlane:
+ * a Plane whose inverse matrix is the identity, or diagonal with entries of
+ * magnitude in [1e-100, 1e100] and a positive y entry b).
+ * With raw.y in (1e-150, 1e150) and |raw.x|, |raw.z| < 1e150:
+ *   |raw|^2 is a positive normal number, 1/|raw| is positive, finite and normal,
+ *   dir.y = raw.y / |raw| > 5e-301, dir is finite and |dir| is within rounding of 1;
+ *   identity matrix: the node test sees dn.y = dir.y * (1/|dir|), a positive number;
+ *   diagonal matrix: it sees dd = dir . inv, dd.y = (+-0) + dir.y * b + (+-0) >= 0 (possibly
+ *   underflowed to zero), |dd| in [0.5e-100, 1.1e100], and d'.y = dd.y * (1/|dd|) >= 0, not NaN;
+ *   either way `d.y > -1e-9` holds, and with o'.y > y the reference returns false.
+ * (Mirror image for raw.y < 0 and o'.y < y.)  o'.y is evaluated literally.  Outside
+ * those bounds — zero, huge, infinite or NaN components — the answer is "don't
+ * know" and the literal evaluation runs.  What this saves: both normalisations
+ * (2 sqrt, 2 divisions) and the matrix products of every ray that hits nothing.
+ * Used by the kernel instances for scenes made of such planes only (PO), where
+ * it removes the whole shadow-ray test of every lit pixel.
+ */
+DEV bool plane_points_away(const DevNode *N, D3 from, D3 raw)
+{
+    const uint32_t fl = N->flags;
+    double oy = (fl & kNodeZeroOffset) ? from.y : from.y - N->off[1];
+    if (!(fl & kNodeIdentityMatrix)) { /* mulvm(o - off, inv).y, literally */
+        const double ox = (fl & kNodeZeroOffset) ? from.x : from.x - N->off[0];
+        const double oz = (fl & kNodeZeroOffset) ? from.z : from.z - N->off[2];
+        oy = ox * N->inv[1] + oy * N->inv[4] + oz * N->inv[7];
+    }
+    const double y = N->g.p[0];
+    const bool sane = (fabs(raw.x) < 1e150) & (fabs(raw.z) < 1e150);
+    const bool up = (raw.y > 1e-150) & (raw.y < 1e150), down = (raw.y < -1e-150) & (raw.y > -1e150);
+    return sane & (((oy > y) & up) | ((oy < y) & down));
+}
+
 /* Node.intersect; `best.dist` is data.dist (world units) in and out. */
 template <int LEVELS, int NEED>
 DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &best)
@@ -706,15 +742,21 @@ DEV uint32_t shadow_cull_mask(const RenderParams &P, int lane, uint32_t l)
 }
 
 /* Scene.testVisibility — rt/scene.d:62-78 */
-template <int LEVELS>
+template <int LEVELS, bool PO>
 DEV bool test_visibility(const Ctx &cx, D3 from, D3 to, uint32_t node_mask)
 {
-    const D3 dir = normalized(to - from);
+    const D3 raw = to - from;
+    const uint32_t nn = cx.n_nodes;
+    uint32_t n = next_node(node_mask, 0);
+    if constexpr (PO) { /* every lane's ray provably leaves the leading planes behind: no ray needed yet */
+        while (n < nn && __all(plane_points_away(cx.nodes + n, from, raw))) n = next_node(node_mask, n + 1);
+        if (n >= nn) return true;
+    }
+    const D3 dir = normalized(raw);
     const RayW ray = make_ray(from, dir);
     Hit temp;
-    temp.dist = mag(to - from);
-    const uint32_t nn = cx.n_nodes;
-    for (uint32_t n = next_node(node_mask, 0); n < nn; n = next_node(node_mask, n + 1)) /* scalar loop, file order */
+    temp.dist = mag(raw);
+    for (; n < nn; n = next_node(node_mask, n + 1)) /* scalar loop, file order */
         if (node_intersect<LEVELS, kBool>(cx, cx.nodes + n, ray, temp)) return false;
     return true;
 }
@@ -818,7 +860,7 @@ DEV F3 tex_color(const RenderParams &P, const Mat &m, double u, double v)
 /* MLC ("multi-light culling"): scenes with more than one light also derive the
  * culling mask of lights 1.. (per sample); single-light scenes run the instance
  * without that code. */
-template <int LEVELS, bool MLC>
+template <int LEVELS, bool MLC, bool PO>
 DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const Hit &h, uint32_t &shadow_rays)
 {
     const bool phong = mat.shader_type == C2RT_SHADER_PHONG;
@@ -833,7 +875,7 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const 
         if (L->lit) {
             const D3 lightPos = ld3(L->pos);
             shadow_rays += 1;
-            if (test_visibility<LEVELS>(cx, h.p + N * 1e-6, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.lane, l) : 0xFFFFFFFFu))) {
+            if (test_visibility<LEVELS, PO>(cx, h.p + N * 1e-6, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.lane, l) : 0xFFFFFFFFu))) {
                 const F3 lightColor = ldf3(L->color);
                 const D3 lightDir = normalized(lightPos - h.p);
                 const double cosTheta = dot(lightDir, N);
@@ -882,11 +924,13 @@ DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &
      * does the same two IEEE subtractions once (c2rt_api.cpp fill_params) */
     const D3 target = upLeft + ld3(P.cam_du) * (x / cam.frame_width) + ld3(P.cam_dv) * (y / cam.frame_height);
     orig = pos;
-    dir = normalized(target - pos);
+    dir = target - pos; /* un-normalised: raytrace() normalises it when a node needs it */
     if constexpr (DOF) {
+        const D3 raw0 = dir;
+        dir = normalized(raw0);
         const D3 rightDir = ld3(cam.right_dir);
         if (offset != 0) orig = orig + rightDir * (offset > 0 ? +cam.stereo_separation : -cam.stereo_separation);
-        if (!cam.dof) return;
+        if (!cam.dof) { dir = raw0; return; }
         const double cosTheta = dot(dir, ld3(cam.front_dir));
         const double M = cam.focal_plane_dist / cosTheta;
         const D3 T = orig + dir * M;
@@ -898,7 +942,7 @@ DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &
         dy *= cam.disc_multiplier;
         orig = pos + rightDir * dx + ld3(cam.up_dir) * dy;
         if (offset != 0) orig = orig + rightDir * (offset > 0 ? +cam.stereo_separation : -cam.stereo_separation);
-        dir = normalized(T - orig);
+        dir = T - orig; /* un-normalised */
     }
 }
 
@@ -909,10 +953,21 @@ DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &
 struct Counters { uint32_t primary, shadow; };
 
 /* trace + raytrace_impl — rt/renderer.d:325-376 (primary rays have depth 0) */
-template <int LEVELS, bool MLC>
-DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt, c2rt_trace_result *probe)
+template <int LEVELS, bool MLC, bool PO>
+DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 raw, Counters &cnt, c2rt_trace_result *probe)
 {
     cnt.primary += 1;
+    const uint32_t nn = P.n_nodes;
+    uint32_t n = next_node(cx.primary_mask, 0);
+    /* planes-only scenes: every lane's ray provably leaves the leading planes behind (sky tiles);
+     * `raw` is the screen ray before normalisation (rt/camera.d:144-147) */
+    if constexpr (PO) {
+        if (!probe) {
+            while (n < nn && __all(plane_points_away(P.nodes + n, o, raw))) n = next_node(cx.primary_mask, n + 1);
+            if (n >= nn) return mkf(0, 0, 0); /* Environment.getEnvironment — rt/environment.d:7-10 */
+        }
+    }
+    const D3 d = normalized(raw);
     const RayW ray = make_ray(o, d);
     Hit best;
     best.dist = 1e99;
@@ -922,8 +977,7 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt,
     best.uv_pending = false;
     best.axis_n = false;
     int closest = -1;
-    const uint32_t nn = P.n_nodes;
-    for (uint32_t n = next_node(cx.primary_mask, 0); n < nn; n = next_node(cx.primary_mask, n + 1)) /* scalar loop, file order */
+    for (; n < nn; n = next_node(cx.primary_mask, n + 1)) /* scalar loop, file order */
         if (node_intersect<LEVELS, kFull>(cx, P.nodes + n, ray, best)) closest = (int)n;
     /* Sphere u,v are read only by textured shaders (and the probe) */
     Mat mat;
@@ -939,7 +993,7 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 d, Counters &cnt,
         probe->ray_dir[0] = d.x; probe->ray_dir[1] = d.y; probe->ray_dir[2] = d.z;
     }
     if (closest < 0) return mkf(0, 0, 0); /* Environment.getEnvironment — rt/environment.d:7-10 */
-    return shade<LEVELS, MLC>(P, cx, mat, d, best, cnt.shadow);
+    return shade<LEVELS, MLC, PO>(P, cx, mat, d, best, cnt.shadow);
 }
 
 /* adjustSaturation + combineStereo — rt/color.d:10-15,77-83 */
@@ -956,7 +1010,7 @@ DEV F3 combine_stereo(F3 l, F3 r)
 }
 
 /* renderSample — rt/renderer.d:254-313 */
-template <int LEVELS, bool DOF, bool MLC>
+template <int LEVELS, bool DOF, bool MLC, bool PO>
 DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, uint64_t pixel, uint32_t tap,
                      Counters &cnt, c2rt_trace_result *probe)
 {
@@ -964,7 +1018,7 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
     D3 o, d;
     if constexpr (!DOF) {
         screen_ray<false>(P, x, y, 0, rng, o, d);
-        return raytrace<LEVELS, MLC>(P, cx, o, d, cnt, probe);
+        return raytrace<LEVELS, MLC, PO>(P, cx, o, d, cnt, probe);
     } else {
         /* renderSampleDof / renderSampleStereo / renderSampleDefault (rt/renderer.d:270-313)
          * as ONE loop around ONE trace call site (five inlined copies of the tracer made
@@ -986,7 +1040,7 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
                     sy = y + jy * 1;
                 }
                 screen_ray<true>(P, sx, sy, stereo ? (e == 0 ? -1 : +1) : 0, rng, o, d);
-                const F3 c = raytrace<LEVELS, MLC>(P, cx, o, d, cnt, e == 0 ? probe : nullptr);
+                const F3 c = raytrace<LEVELS, MLC, PO>(P, cx, o, d, cnt, e == 0 ? probe : nullptr);
                 sample = e == 0 ? c : combine_stereo(sample, c);
             }
             if (!dof) return sample;
@@ -1006,7 +1060,7 @@ __constant__ double k_aa_y[5] = {0.0, 0.3, 0.0, 0.6, 0.6};
  * reference's order and the pixel is written once (12 B of HBM traffic per
  * pixel).  One workgroup = one wavefront = one 8x8 tile.
  */
-template <int LEVELS, bool DOF, bool MLC>
+template <int LEVELS, bool DOF, bool MLC, bool PO>
 DEV void render_body(const RenderParams &P)
 {
     extern __shared__ __align__(16) char lds_all[];
@@ -1084,7 +1138,7 @@ DEV void render_body(const RenderParams &P)
     F3 accum = mkf(0, 0, 0);
 #pragma unroll 1
     for (uint32_t s = 0; s < ntaps; ++s) {
-        const F3 c = render_sample<LEVELS, DOF, MLC>(P, cx, (double)sx + k_aa_x[s], (double)sy + k_aa_y[s], pixel, s, cnt, nullptr);
+        const F3 c = render_sample<LEVELS, DOF, MLC, PO>(P, cx, (double)sx + k_aa_x[s], (double)sy + k_aa_y[s], pixel, s, cnt, nullptr);
         accum = s == 0 ? c : accum + c;
     }
     if (ntaps > 1) accum = accum / (float)ntaps; /* `accum / 5`: Color / float */
@@ -1103,7 +1157,7 @@ DEV void render_body(const RenderParams &P)
 template <int LEVELS, bool DOF, bool MLC>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const RenderParams P)
 {
-    render_body<LEVELS, DOF, MLC>(P);
+    render_body<LEVELS, DOF, MLC, false>(P);
 }
 
 /* The depth-of-field / stereo instance carries the lens sampling state on top of
@@ -1111,7 +1165,15 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const Re
 template <int LEVELS>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_DOF render_kernel_dof(const RenderParams P)
 {
-    render_body<LEVELS, true, false>(P);
+    render_body<LEVELS, true, false, false>(P);
+}
+
+/* Scenes made of axis planes only (RenderParams::planes_only — lecture4.sdl, zaphod.sdl): the
+ * instances in which a plane's miss is decided before the ray is normalised (plane_points_away). */
+template <bool DOF>
+__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel_planes(const RenderParams P)
+{
+    render_body<0, DOF, false, true>(P); /* planes have no boxes: no culling masks, hence no MLC */
 }
 
 /* renderPixel — rt/renderer.d:46-57: one lane, one sample, full trace result */
@@ -1130,7 +1192,7 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.shadow_mask0 = 0xFFFFFFFFu;
     Counters cnt = {0, 0};
     const uint64_t pixel = (uint64_t)P.probe_y * P.width + (uint64_t)P.probe_x;
-    const F3 c = render_sample<LEVELS, DOF, false>(P, cx, (double)P.probe_x, (double)P.probe_y, pixel, 0, cnt, P.probe_out);
+    const F3 c = render_sample<LEVELS, DOF, false, false>(P, cx, (double)P.probe_x, (double)P.probe_y, pixel, 0, cnt, P.probe_out);
     P.probe_out->color[0] = c.r;
     P.probe_out->color[1] = c.g;
     P.probe_out->color[2] = c.b;
@@ -1199,6 +1261,15 @@ int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, vo
 #endif
     const dim3 grid(p.blocks_x * tiles_y_pad), block(kBlockThreads);
     const size_t lds = (size_t)C2RT_UNIT * kCsgLdsPerLevel * kWavesPerBlock;
+#if C2RT_UNIT == 0
+    if (p.planes_only) {
+        if (dof_or_stereo)
+            hipLaunchKernelGGL((render_kernel_planes<true>), grid, block, lds, s, p);
+        else
+            hipLaunchKernelGGL((render_kernel_planes<false>), grid, block, lds, s, p);
+        return (int)hipGetLastError();
+    }
+#endif
     if (dof_or_stereo)
         hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT>), grid, block, lds, s, p);
     else if (p.n_cull_lights > 1)

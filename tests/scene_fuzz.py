@@ -84,3 +84,70 @@ def many_lights_scene_sdl(seed):
     head, rest = text.split("  Lights {\n", 1)
     _, tail = rest.split("\n  }\n", 1)
     return head + "  Lights {\n    " + "\n    ".join(lights) + "\n  }\n" + tail
+
+
+def planes_scene_sdl(seed):
+    """Scenes made of Plane nodes only (the kernel instances that decide a plane's miss before the
+    ray is normalised): 1-3 planes, bounded or not, under identity / diagonal scale (negative in
+    x or z, non-uniform) / translate / (sometimes) the "rotate" entry the loader applies as a
+    scale; lights above, below, level with a plane, absurdly far (1e155, beyond the shortcut's
+    bounds) or absurdly close; cameras above, below and looking up at the sky."""
+    r = random.Random(20_000 + seed)
+    geoms, nodes = [], []
+    for i in range(r.randint(1, 3)):
+        lim = "; limit %.6g" % r.uniform(40, 400) if r.random() < 0.4 else ""
+        geoms.append('Plane "p%d" { y %.6g%s }' % (i, r.choice([0, -0.01, r.uniform(-30, 60)]), lim))
+        xf = ""
+        k = r.random()
+        if k < 0.35:
+            sx, sy, sz = (r.choice([-1, 1]) * r.uniform(0.2, 12), r.uniform(0.2, 12), r.choice([-1, 1]) * r.uniform(0.2, 12))
+            xf += "; scale %.6g %.6g %.6g" % (sx, sy, sz)
+        elif k < 0.45:
+            xf += "; scale 10 10 10"
+        elif k < 0.5:
+            xf += "; scale %.6g %.6g %.6g" % (r.uniform(0.5, 2), -r.uniform(0.5, 2), r.uniform(0.5, 2))   # negative y: not an axis plane
+        if r.random() < 0.1:
+            xf += "; rotate %s" % _v(r, 0.7, 1.4)
+        if r.random() < 0.4:
+            xf += "; translate %s" % _v(r, -40, 40)
+        nodes.append('Node "n%d" { geometry "p%d"; shader "s%d"%s }' % (i, i, r.randint(0, 5), xf))
+    textures = ['Checker "chk" { color1 %s; color2 %s; size %.6g }' % (_v(r, 0, 1), _v(r, 0, 1), r.uniform(3, 30)),
+                'Procedure2 "proc" { freqU %s; freqV %s; colorU { color %s; color %s; color %s }; colorV { color %s; color %s; color %s } }'
+                % (_v(r, 0.01, 0.5), _v(r, 0.01, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5)),
+                'BitmapTexture "bmp" { file "floor.bmp"; scaling %.6g }' % r.uniform(0.005, 0.05)]
+    shaders = ['Lambert "s0" { texture "chk" }', 'Lambert "s1" { texture "proc" }', 'Lambert "s2" { texture "bmp" }',
+               'Lambert "s3" { color %s }' % _v(r, 0.1, 1),
+               'Phong "s4" { color %s; exponent %.6g; strength %.6g }' % (_v(r, 0.1, 1), r.uniform(2, 90), r.uniform(0.2, 1)),
+               'Phong "s5" { texture "bmp"; exponent %.6g }' % r.uniform(5, 40)]
+    lights = []
+    for i in range(r.randint(1, 3)):
+        k = r.random()
+        if k < 0.5:
+            pos = "%.6g %.6g %.6g" % (r.uniform(-200, 200), r.uniform(20, 300), r.uniform(-200, 200))
+        elif k < 0.65:
+            pos = "%.6g %.6g %.6g" % (r.uniform(-200, 200), -r.uniform(20, 300), r.uniform(-200, 200))      # below
+        elif k < 0.75:
+            pos = "%.6g %.6g %.6g" % (r.uniform(-200, 200), r.choice([0, -0.01, 1e-160, -1e-160]), r.uniform(-200, 200))  # level
+        elif k < 0.85:
+            pos = "%s %s %s" % (r.choice(["1e155", "-3e160", "5"]), r.choice(["1e155", "2e151", "7e149"]), r.choice(["-1e155", "40"]))
+        elif k < 0.93:
+            pos = "%.6g %s %.6g" % (r.uniform(-50, 50), r.choice(["1e-155", "3e-151", "1e-149"]), r.uniform(-50, 50))
+        else:
+            pos = "1e308 1e308 -1e308"
+        lights.append('PointLight "l%d" { pos %s; color %s; power %s }' % (i, pos, _v(r, 0.3, 1), r.choice(["50000", "1e300", "8000"])))
+    if r.random() < 0.25:   # below the plane(s), or looking up
+        cam = "Camera { pos %.6g %.6g %.6g; yaw %.6g; pitch %.6g; roll %.6g; fov %.6g }" % (
+            r.uniform(-30, 30), -r.uniform(5, 90), r.uniform(-160, -90), r.uniform(-15, 15), r.uniform(-10, 40), r.uniform(-5, 5), r.uniform(50, 95))
+    else:
+        cam = "Camera { pos %.6g %.6g %.6g; yaw %.6g; pitch %.6g; roll %.6g; fov %.6g }" % (
+            r.uniform(-30, 30), r.uniform(3, 120), r.uniform(-160, -20), r.uniform(-25, 25), r.uniform(-60, 15), r.uniform(-8, 8), r.uniform(40, 100))
+    return "\n".join([
+        "Scene {", '  Name "planes%d"' % seed,
+        "  GlobalSettings { frameWidth 96; frameHeight 72; AAEnabled %s; ambientLightColor %s }" % (r.choice(["false", "true"]), _v(r, 0, 0.2)),
+        "  " + cam,
+        "  Lights {\n    " + "\n    ".join(lights) + "\n  }",
+        "  Geometries {\n    " + "\n    ".join(geoms) + "\n  }",
+        "  Textures {\n    " + "\n    ".join(textures) + "\n  }",
+        "  Shaders {\n    " + "\n    ".join(shaders) + "\n  }",
+        "  Nodes {\n    " + "\n    ".join(nodes) + "\n  }",
+        "}", ""])
