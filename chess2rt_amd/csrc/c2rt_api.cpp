@@ -8,6 +8,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -47,6 +48,9 @@ struct c2rt_ctx {
     /* world-space corners of every node's padded bounding box (for the per-frame
      * screen rectangles); node_boxed[n] = 0: unbounded, never culled */
     uint32_t planes_only = 0;          /* every node is an axis plane (kNodeAxisPlane) */
+    int32_t ground_node = -1;          /* see RenderParams::ground_node */
+    double ground_y = 0;
+    double *shadow_rects = nullptr;    /* [kMaxCullNodes][4] */
     std::vector<double> node_box;  /* [n_nodes][8][3] */
     std::vector<double> light_pos; /* [n_lights][3] host copy for the per-frame shadow-cull thresholds */
     std::vector<uint8_t> node_boxed;
@@ -264,6 +268,9 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
     p.blocks_x = (p.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     p.seed = o->seed;
     p.planes_only = ctx->planes_only;
+    p.ground_node = ctx->ground_node;
+    p.ground_y = ctx->ground_y;
+    p.shadow_rects = ctx->shadow_rects;
     p.n_cull = 0;
     if (!cam->dof && cam->stereo_separation == 0 && !o->prepass_bucket) {
         /* up to the last bounded node; nothing bounded => no per-wave work at all */
@@ -453,7 +460,7 @@ void c2rt_destroy(c2rt_ctx *ctx)
         if (e) (void)hipEventDestroy(e);
     for (const auto &pb : ctx->pinned) (void)hipHostUnregister(pb.first);
     void *bufs[] = {ctx->geoms, ctx->nodes, ctx->shaders, ctx->textures, ctx->lights, ctx->texels,
-                    ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut};
+                    ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut, ctx->shadow_rects};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete ctx;
@@ -645,6 +652,81 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
     }
 
     ctx->light_pos.assign(s->light_pos, s->light_pos + 3 * (size_t)s->n_lights);
+
+    /* Ground-plane shadow culling towards light 0 (RenderParams::ground_node): the first Plane node
+     * under an identity matrix with zero offset is the ground; every boxed node gets the rectangle
+     * (in the plane's x, z) of its padded world box projected from the light onto the plane.
+     * Let Q be a point of the box on a shadow segment from P' = P + N*1e-6 (P on the plane) to the
+     * light L: L, Q and P' are collinear, so the central projection of Q from L onto the plane is
+     * the point where the line L-P' meets it — within 1e-6 * (horizontal / vertical extent of the
+     * segment) of P.  Hence P lies in the projected box grown by that much; the rectangle is padded
+     * by 1e-5 * (1 + slope) + 1e-9 * scale, far above rounding in P.  Defined only when the light is
+     * above the plane and the whole box lies strictly between plane and light (or the mirror image
+     * below the plane); otherwise the rectangle is everything. */
+    {
+        std::vector<double> rects((size_t)kMaxCullNodes * 4);
+        for (int n = 0; n < kMaxCullNodes; ++n) {
+            rects[4 * n + 0] = rects[4 * n + 2] = -HUGE_VAL;
+            rects[4 * n + 1] = rects[4 * n + 3] = HUGE_VAL;
+        }
+        ctx->ground_node = -1;
+        for (uint32_t n = 0; n < s->n_nodes && n < (uint32_t)kMaxCullNodes; ++n) {
+            const DevNode &d = nodes[n];
+            if (d.g.type == C2RT_GEOM_PLANE && (d.flags & kNodeIdentityMatrix) && (d.flags & kNodeZeroOffset) && std::isfinite(d.g.p[0])) {
+                ctx->ground_node = (int32_t)n;
+                ctx->ground_y = d.g.p[0];
+                break;
+            }
+        }
+        if (ctx->ground_node >= 0 && s->n_lights > 0) {
+            const double *L = s->light_pos;
+            const double y0 = ctx->ground_y, h = L[1] - y0; /* light height over the plane (signed) */
+            for (uint32_t n = 0; n < s->n_nodes && n < (uint32_t)kMaxCullNodes; ++n) {
+                if (!ctx->node_boxed[n] || !std::isfinite(h) || h == 0) continue;
+                /* axis-aligned hull of the node's (possibly sheared) world box */
+                double bmin[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, bmax[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+                for (int k = 0; k < 8; ++k)
+                    for (int j = 0; j < 3; ++j) {
+                        const double v = ctx->node_box[((size_t)n * 8 + k) * 3 + j];
+                        bmin[j] = std::min(bmin[j], v);
+                        bmax[j] = std::max(bmax[j], v);
+                    }
+                /* heights as t = (y - y0) / h: 0 on the plane, 1 at the light's height.  Shadow segments
+                 * start within 1e-6 of the plane and end at the light: what the box has beyond the plane
+                 * (t < 0) is out of their reach, so it is clipped there (with slack) */
+                double t_lo = (bmin[1] - y0) / h, t_hi = (bmax[1] - y0) / h;
+                if (t_lo > t_hi) std::swap(t_lo, t_hi);
+                const double slack = 1e-5 * (1.0 + std::fabs(y0)) / std::fabs(h);
+                t_lo = std::max(t_lo, -slack);
+                if (!(t_hi < 1 - 1e-9) || !(t_hi >= t_lo)) continue; /* reaches the light's height, or wholly beyond the plane: no rectangle */
+                double lo[2] = {HUGE_VAL, HUGE_VAL}, hi[2] = {-HUGE_VAL, -HUGE_VAL};
+                double scale = std::fabs(y0) + std::fabs(L[0]) + std::fabs(L[1]) + std::fabs(L[2]);
+                bool ok = true;
+                for (int k = 0; k < 8 && ok; ++k) {
+                    const double wx = (k & 1) ? bmax[0] : bmin[0], wz = (k & 2) ? bmax[2] : bmin[2], t = (k & 4) ? t_hi : t_lo;
+                    const double sfac = 1.0 / (1.0 - t);         /* L + (w - L) * sfac lies on the plane */
+                    const double px = L[0] + (wx - L[0]) * sfac, pz = L[2] + (wz - L[2]) * sfac;
+                    ok = std::isfinite(px) && std::isfinite(pz);
+                    lo[0] = std::min(lo[0], px); hi[0] = std::max(hi[0], px);
+                    lo[1] = std::min(lo[1], pz); hi[1] = std::max(hi[1], pz);
+                    scale = std::max(scale, std::fabs(px) + std::fabs(pz));
+                }
+                if (!ok) continue;
+                /* slope of the steepest-sideways shadow segment that can end in the rectangle */
+                const double dx = std::max(std::fabs(lo[0] - L[0]), std::fabs(hi[0] - L[0]));
+                const double dz = std::max(std::fabs(lo[1] - L[2]), std::fabs(hi[1] - L[2]));
+                const double slope = std::sqrt(dx * dx + dz * dz) / std::fabs(h);
+                const double pad = 1e-5 * (1.0 + slope) + 1e-9 * scale;
+                if (!std::isfinite(pad)) continue;
+                rects[4 * n + 0] = lo[0] - pad; rects[4 * n + 1] = hi[0] + pad;
+                rects[4 * n + 2] = lo[1] - pad; rects[4 * n + 3] = hi[1] + pad;
+            }
+        } else {
+            ctx->ground_node = -1;
+        }
+        int st0;
+        if ((st0 = upload(ctx, &ctx->shadow_rects, rects)) != C2RT_OK) return st0;
+    }
 
     int st;
     if ((st = upload(ctx, &ctx->geoms, geoms)) != C2RT_OK) return st;

@@ -163,6 +163,15 @@ struct RenderParams {
     /* every node is an "axis plane" (kNodeAxisPlane): the launcher picks the kernel instance that
      * decides plane misses from the un-normalised ray direction (plane_points_away) */
     uint32_t planes_only;
+    /* "Ground plane" shadow culling (c2rt_api.cpp: ground_shadow_rects).  ground_node >= 0: node
+     * ground_node is a Plane under an identity matrix with zero offset, at height ground_y.  In a
+     * tile whose primary rays can reach that node only, every hit point lies on the plane inside the
+     * tile's footprint there, and a shadow ray towards light 0 can only meet node n if the footprint
+     * meets shadow_rects[n] = {x0, x1, z0, z1}: the padded box of node n projected from the light onto
+     * the plane (+-inf when that projection is not defined). */
+    int32_t ground_node;
+    double ground_y;
+    const double *shadow_rects;    /* [kMaxCullNodes][4], device memory (scene constant) */
     uint32_t tiles_x, tiles_y;     /* tile grid over the LOCAL rows */
     uint32_t blocks_x;             /* ceil(tiles_x / kWavesPerBlock) */
     uint64_t seed;

@@ -98,6 +98,12 @@ DEV F3 operator*(F3 a, F3 b) { return mkf(a.r * b.r, a.g * b.g, a.b * b.b); }
 DEV F3 operator*(F3 a, float f) { return mkf(a.r * f, a.g * f, a.b * f); }
 DEV F3 operator/(F3 a, float f) { return mkf(a.r / f, a.g / f, a.b / f); }
 
+/* a double held by lane `l`, as a wave-uniform value */
+DEV double read_lane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 /* x86 cvttsd2si / cvttss2si results for out-of-range inputs, which is what
  * the reference binary computes for cast(int) / cast(size_t). */
 DEV int d2i_x86(double d)
@@ -1096,6 +1102,34 @@ DEV void render_body(const RenderParams &P)
             lane_rect(P, lane, mine, r0, r1, r2, r3);
             pmask = (uint32_t)__ballot(!mine || !(r2 <= tx0 || r0 >= tx0 + kTileW || r3 <= ty0 || r1 > ty1));
             smask0 = shadow_cull_mask(P, lane, 0);
+            /* Ground-plane refinement (RenderParams::ground_node): if this tile's primary rays can only
+             * reach the ground plane, all its hit points lie inside the tile's footprint on that plane
+             * — the convex image of the pixel rectangle (+1 px all round; the AA taps reach 0.6 px),
+             * provided all four corner rays meet the plane in front of the eye — and a node whose
+             * shadow rectangle misses the footprint's bounding rectangle cannot occlude any of them. */
+            const int gnode = P.ground_node;
+            const uint32_t nn = P.n_nodes;
+            if (gnode >= 0 && nn <= 32u && (pmask & (0xFFFFFFFFu >> (32u - nn))) == (1u << gnode)) {
+                const D3 pos = ld3(P.cam.pos), ul = ld3(P.cam.up_left), du = ld3(P.cam_du), dv = ld3(P.cam_dv);
+                const double gy = P.ground_y;
+                /* lane k & 3 intersects corner k's ray with the plane; lanes 0..3 are then read back */
+                const int k = lane & 3;
+                const double sx = (k & 1) ? (double)(tx0 + kTileW + 1) : (double)(tx0 - 1);
+                const double sy = (k & 2) ? (double)(ty1 + 2) : (double)(ty0 - 1);
+                const D3 dir = ul + du * (sx / P.cam.frame_width) + dv * (sy / P.cam.frame_height) - pos;
+                const double t = (gy - pos.y) / dir.y;
+                bool ok = (__ballot((t > 0) & (t < 1e300)) & 0xFull) == 0xFull;
+                const double hx = pos.x + dir.x * t, hz = pos.z + dir.z * t;
+                const double hx0 = read_lane(hx, 0), hx1 = read_lane(hx, 1), hx2 = read_lane(hx, 2), hx3 = read_lane(hx, 3);
+                const double hz0 = read_lane(hz, 0), hz1 = read_lane(hz, 1), hz2 = read_lane(hz, 2), hz3 = read_lane(hz, 3);
+                const double fx0 = fmin(fmin(hx0, hx1), fmin(hx2, hx3)), fx1 = fmax(fmax(hx0, hx1), fmax(hx2, hx3));
+                const double fz0 = fmin(fmin(hz0, hz1), fmin(hz2, hz3)), fz1 = fmax(fmax(hz0, hz1), fmax(hz2, hz3));
+                const double padx = 1e-9 * (fabs(fx0) + fabs(fx1)), padz = 1e-9 * (fabs(fz0) + fabs(fz1));
+                ok = ok & (fx0 <= fx1) & (fz0 <= fz1) & (fabs(fx0) < 1e300) & (fabs(fx1) < 1e300) & (fabs(fz0) < 1e300) & (fabs(fz1) < 1e300);
+                const double *sr = P.shadow_rects + 4 * (mine ? lane : 0);
+                const bool apart = (sr[1] < fx0 - padx) | (sr[0] > fx1 + padx) | (sr[3] < fz0 - padz) | (sr[2] > fz1 + padz);
+                smask0 &= ~(uint32_t)__ballot(ok & mine & apart);
+            }
         }
     }
 

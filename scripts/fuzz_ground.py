@@ -1,0 +1,21 @@
+"""Offline sweep of ground-plane scenes (ground shadow rectangles) against the oracle."""
+import os, sys, shutil, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
+import chess2rt_amd as c2, oracle_lib as orc
+from scene_fuzz import ground_scene_sdl
+d = '/tmp/fzg'; os.makedirs(d, exist_ok=True); shutil.copy(ROOT + '/tests/golden/scenes/floor.bmp', d + '/floor.bmp')
+ctx = c2.Context(0); bad = 0; nne = 0
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+for seed in range(1000, 1000 + N):
+    open(d + "/f.sdl", "w").write(ground_scene_sdl(seed))
+    s = c2.parseSceneFromFile(d + '/f.sdl')
+    s.setFrameSize(*( (96, 72) if seed % 2 else (160, 120) )); cam = s.beginFrame(); opts = s.renderOpts(count_rays=1)
+    ctx.uploadScene(s.desc); a = ctx.renderFrame(cam, opts); pr, sh = ctx.rayStats(); st = {}
+    r = orc.render_frame(s.desc, cam, opts, 8, st)
+    dd = np.abs(a.astype(np.float64) - r.astype(np.float64)); dd = np.where(np.isnan(a) & np.isnan(r), 0, dd)
+    nne += int((dd != 0).sum())
+    if not np.array_equal(np.isnan(a), np.isnan(r)) or np.nanmax(dd) > 1e-4 or (pr, sh) != (st['primary'], st['shadow']):
+        bad += 1; print('MISMATCH seed', seed, float(np.nanmax(dd)), (pr, sh), st)
+    if seed % 250 == 0: print('progress', seed, bad, nne, flush=True)
+print('done: bad scenes', bad, 'differing floats', nne)

@@ -151,3 +151,73 @@ def planes_scene_sdl(seed):
         "  Shaders {\n    " + "\n    ".join(shaders) + "\n  }",
         "  Nodes {\n    " + "\n    ".join(nodes) + "\n  }",
         "}", ""])
+
+
+def ground_scene_sdl(seed):
+    """One ground plane (identity node 0) plus 2-6 small objects above, below, resting on or cutting
+    through it; light 0 above, grazing, below the ground, among or inside the objects; camera above
+    or below the ground: exercises the ground-plane shadow rectangles (projection of each node's box
+    from the light onto the plane) against the literal shadow rays."""
+    r = random.Random(30_000 + seed)
+    gy = r.choice([0, -0.01, r.uniform(-10, 10)])
+    lim = "; limit %.6g" % r.uniform(150, 600) if r.random() < 0.2 else ""
+    geoms = ['Plane "ground" { y %.6g%s }' % (gy, lim)]
+    nodes = ['Node "n0" { geometry "ground"; shader "s%d" }' % r.choice([0, 1, 2, 3])]
+    for i in range(r.randint(2, 6)):
+        kind = r.choice(["Sphere", "Cube", "Csg"])
+        size = r.uniform(4, 25)
+        k = r.random()
+        cy = gy + (size * r.uniform(1.0, 4.0) if k < 0.55 else size * r.uniform(-0.5, 1.0) if k < 0.85 else -size * r.uniform(1.0, 3.0))
+        c = "%.6g %.6g %.6g" % (r.uniform(-70, 70), cy, r.uniform(-40, 90))
+        if kind == "Sphere":
+            geoms.append('Sphere "g%d" { center %s; R %.6g }' % (i, c, size))
+        elif kind == "Cube":
+            geoms.append('Cube "g%d" { center %s; side %.6g }' % (i, c, 2 * size))
+        else:
+            geoms.append('Cube "g%da" { center %s; side %.6g }' % (i, c, 2 * size))
+            geoms.append('Sphere "g%db" { center %s; R %.6g }' % (i, c, size * r.uniform(0.9, 1.35)))
+            geoms.append('%s "g%d" { left "g%da"; right "g%db" }' % (r.choice(["CsgDiff", "CsgInter", "CsgUnion"]), i, i, i))
+        xf = ""
+        if r.random() < 0.3:
+            xf += "; scale %s" % _v(r, 0.6, 1.8)
+        if r.random() < 0.3:
+            xf += "; translate %s" % _v(r, -25, 25)
+        nodes.append('Node "n%d" { geometry "g%d"; shader "s%d"%s }' % (i + 1, i, r.randint(0, 5), xf))
+    textures = ['Checker "chk" { color1 %s; color2 %s; size %.6g }' % (_v(r, 0, 1), _v(r, 0, 1), r.uniform(3, 30)),
+                'Procedure2 "proc" { freqU %s; freqV %s; colorU { color %s; color %s; color %s }; colorV { color %s; color %s; color %s } }'
+                % (_v(r, 0.01, 0.5), _v(r, 0.01, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5)),
+                'BitmapTexture "bmp" { file "floor.bmp"; scaling %.6g }' % r.uniform(0.005, 0.05)]
+    shaders = ['Lambert "s0" { texture "chk" }', 'Lambert "s1" { texture "proc" }', 'Lambert "s2" { texture "bmp" }',
+               'Lambert "s3" { color %s }' % _v(r, 0.1, 1),
+               'Phong "s4" { color %s; exponent %.6g; strength %.6g }' % (_v(r, 0.1, 1), r.uniform(2, 90), r.uniform(0.2, 1)),
+               'Phong "s5" { texture "bmp"; exponent %.6g }' % r.uniform(5, 40)]
+    k = r.random()
+    if k < 0.4:
+        lpos = "%.6g %.6g %.6g" % (r.uniform(-200, 200), gy + r.uniform(60, 400), r.uniform(-200, 300))
+    elif k < 0.6:
+        lpos = "%.6g %.6g %.6g" % (r.uniform(-300, 300), gy + r.uniform(0.5, 12), r.uniform(-300, 300))     # grazing
+    elif k < 0.75:
+        lpos = "%.6g %.6g %.6g" % (r.uniform(-60, 60), gy + r.uniform(5, 60), r.uniform(-30, 80))           # among / inside the objects
+    elif k < 0.9:
+        lpos = "%.6g %.6g %.6g" % (r.uniform(-200, 200), gy - r.uniform(1, 200), r.uniform(-200, 300))      # below the ground
+    else:
+        lpos = "%.6g %.6g %.6g" % (r.uniform(-200, 200), gy, r.uniform(-200, 300))                          # in the plane
+    lights = ['PointLight "l0" { pos %s; color 1 1 1; power %.6g }' % (lpos, r.uniform(8000, 90000))]
+    for i in range(r.randint(0, 2)):
+        lights.append('PointLight "l%d" { pos %s; color %s; power %.6g }' % (i + 1, _v(r, -150, 150), _v(r, 0.3, 1), r.uniform(8000, 60000)))
+    if r.random() < 0.2:
+        cam = "Camera { pos %.6g %.6g %.6g; yaw %.6g; pitch %.6g; roll %.6g; fov %.6g }" % (
+            r.uniform(-30, 30), gy - r.uniform(5, 60), r.uniform(-160, -90), r.uniform(-15, 15), r.uniform(-5, 35), r.uniform(-5, 5), r.uniform(50, 95))
+    else:
+        cam = "Camera { pos %.6g %.6g %.6g; yaw %.6g; pitch %.6g; roll %.6g; fov %.6g }" % (
+            r.uniform(-40, 40), gy + r.uniform(3, 120), r.uniform(-180, -60), r.uniform(-25, 25), r.uniform(-50, 5), r.uniform(-8, 8), r.uniform(40, 100))
+    return "\n".join([
+        "Scene {", '  Name "ground%d"' % seed,
+        "  GlobalSettings { frameWidth 96; frameHeight 72; AAEnabled %s; ambientLightColor %s }" % (r.choice(["false", "false", "true"]), _v(r, 0, 0.2)),
+        "  " + cam,
+        "  Lights {\n    " + "\n    ".join(lights) + "\n  }",
+        "  Geometries {\n    " + "\n    ".join(geoms) + "\n  }",
+        "  Textures {\n    " + "\n    ".join(textures) + "\n  }",
+        "  Shaders {\n    " + "\n    ".join(shaders) + "\n  }",
+        "  Nodes {\n    " + "\n    ".join(nodes) + "\n  }",
+        "}", ""])

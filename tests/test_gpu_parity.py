@@ -566,3 +566,34 @@ def test_planes_only_scenes(gpu_ctx, tmp_path, scenes_dir):
         assert (pr, sh) == (st["primary"], st["shadow"]), seed
         differing += nne
     print("planes-only fuzz: %d differing floats over 80 scenes" % differing)
+
+
+def test_ground_plane_shadow_rectangles(gpu_ctx, tmp_path, scenes_dir):
+    """Ground plane + small objects above / below / through it, light 0 above, grazing, below the
+    ground or among the objects, camera above or below: tiles that only see the ground drop the
+    nodes whose light-projected box misses the tile's footprint; frames must stay identical."""
+    import shutil
+
+    from scene_fuzz import ground_scene_sdl
+
+    shutil.copy(os.path.join(scenes_dir, "floor.bmp"), tmp_path / "floor.bmp")
+    differing = 0
+    for seed in range(80):
+        path = tmp_path / ("ground%d.sdl" % seed)
+        path.write_text(ground_scene_sdl(seed))
+        scene = c2.parseSceneFromFile(str(path))
+        if seed % 3 == 0:
+            scene.setFrameSize(163, 101)
+        cam = scene.beginFrame()
+        opts = scene.renderOpts(count_rays=1)
+        gpu_ctx.uploadScene(scene.desc)
+        a = gpu_ctx.renderFrame(cam, opts)
+        pr, sh = gpu_ctx.rayStats()
+        st = {}
+        ref = orc.render_frame(scene.desc, cam, opts, 2, st)
+        assert np.array_equal(np.isnan(a), np.isnan(ref)), seed
+        md, nbad, nne = maxdiff(a, ref)
+        assert md <= TOL, (seed, md)
+        assert (pr, sh) == (st["primary"], st["shadow"]), seed
+        differing += nne
+    print("ground fuzz: %d differing floats over 80 scenes" % differing)
