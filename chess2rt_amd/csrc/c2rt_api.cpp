@@ -181,6 +181,39 @@ BoundInfo bound_of(const c2rt_scene_desc *s, int32_t g, std::vector<BoundInfo> &
     return b;
 }
 
+/* Object-space axis-aligned box with the same contract as the bounding sphere above — a ray
+ * (segment) that does not enter it cannot make Geometry.intersect return true — but tight: the
+ * sphere's own box, the cube itself, the left child's box for an Inter/Diff with shortcut A
+ * (no left hit => false; left hits beyond the segment put the winner beyond it too), the hull of
+ * both children otherwise.  It feeds the per-frame screen rectangles and the shadow rectangles,
+ * where the bounding sphere of a cube costs a factor 1.7 per axis.  Call after bound_of (flags). */
+struct BoxInfo { bool done = false, bounded = false; double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; };
+
+BoxInfo box_of(const c2rt_scene_desc *s, int32_t g, std::vector<BoxInfo> &memo, const std::vector<DevGeom> &geoms)
+{
+    if (memo[g].done) return memo[g];
+    BoxInfo b;
+    b.done = true;
+    const int t = s->geom_type[g];
+    const double *p = s->geom_param + 4 * (size_t)g;
+    if (t == C2RT_GEOM_SPHERE || t == C2RT_GEOM_CUBE) {
+        b.bounded = std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]) && std::isfinite(p[3]);
+        const double e = t == C2RT_GEOM_SPHERE ? std::fabs(p[3]) : std::fabs(p[3]) * 0.5;
+        for (int i = 0; i < 3; ++i) { b.lo[i] = p[i] - e; b.hi[i] = p[i] + e; }
+    } else if (is_csg(t)) {
+        const BoxInfo bl = box_of(s, s->geom_child[2 * g], memo, geoms), br = box_of(s, s->geom_child[2 * g + 1], memo, geoms);
+        if ((geoms[g].flags & kCsgShortA) && bl.bounded) {
+            b = bl;
+        } else if (bl.bounded && br.bounded) {
+            b.bounded = true;
+            for (int i = 0; i < 3; ++i) { b.lo[i] = std::min(bl.lo[i], br.lo[i]); b.hi[i] = std::max(bl.hi[i], br.hi[i]); }
+        }
+        b.done = true;
+    } /* plane: unbounded */
+    memo[g] = b;
+    return b;
+}
+
 /* convertTo8bit_sRGB — rt/color.d:194-207 (note the 12.02) and the 4097-entry
  * cache built by the module constructor rt/color.d:224-228 */
 void build_srgb_lut(uint8_t *lut)
@@ -620,28 +653,38 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         else ctx->planes_only = 0;
     }
 
-    /* world-space bounding boxes of the nodes: object-space bounding sphere -> its
-     * axis-aligned box -> the 8 corners through Transform.point (affine: hull preserved) */
+    /* world-space bounding boxes of the nodes: object-space box (box_of), padded -> the 8
+     * corners through Transform.point (affine: hull preserved) */
     ctx->node_box.assign((size_t)s->n_nodes * 24, 0.0);
     ctx->node_boxed.assign(s->n_nodes, 0);
+    std::vector<BoxInfo> boxes(s->n_geoms);
     for (uint32_t n = 0; n < s->n_nodes; ++n) {
         const DevGeom &g = nodes[n].g;
         if (!(g.flags & kGeomBounded)) continue;
+        const BoxInfo bx = box_of(s, nodes[n].geom, boxes, geoms);
+        if (!bx.bounded) continue;
         /* a singular / non-finite transform (e.g. `scale 0 0 0`) sends NaN rays into the
          * geometry, whose hits follow no geometric bound: never cull such a node */
         bool sane = true;
         for (int i = 0; i < 9; ++i) sane = sane && std::isfinite(nodes[n].m[i]) && std::isfinite(nodes[n].inv[i]) && std::isfinite(nodes[n].tinv[i]);
         for (int i = 0; i < 3; ++i) sane = sane && std::isfinite(nodes[n].off[i]);
         if (!sane) continue;
-        /* shadow rays start 1e-6 (world units) off the surface (rt/shader.d:88): pad by
+        /* pads: the same relative pad as the bounding sphere (the tests run in fp64 on coordinates
+         * of this magnitude); shadow rays start 1e-6 (world units) off the surface (rt/shader.d:88):
          * 4e-6 world units = 4e-6 * |M^-1|_F object units (|M^-1|_F >= 1 / smallest scale) */
         double inv_norm = 0;
         for (int i = 0; i < 9; ++i) inv_norm += nodes[n].inv[i] * nodes[n].inv[i];
         inv_norm = std::sqrt(inv_norm);
-        const double r = std::sqrt(g.bound[3]) + 4e-6 * (inv_norm > 1 ? inv_norm : 1.0);
-        bool finite = std::isfinite(r);
+        double mag = 0, ext = 0;
+        for (int i = 0; i < 3; ++i) {
+            mag += std::fmax(std::fabs(bx.lo[i]), std::fabs(bx.hi[i]));
+            ext = std::fmax(ext, bx.hi[i] - bx.lo[i]);
+        }
+        const double pad = 1e-6 * ext + 1e-6 * mag + 1e-9 + 4e-6 * (inv_norm > 1 ? inv_norm : 1.0);
+        bool finite = std::isfinite(pad);
         for (int k = 0; k < 8 && finite; ++k) {
-            const double q[3] = {g.bound[0] + ((k & 1) ? r : -r), g.bound[1] + ((k & 2) ? r : -r), g.bound[2] + ((k & 4) ? r : -r)};
+            const double q[3] = {(k & 1) ? bx.hi[0] + pad : bx.lo[0] - pad, (k & 2) ? bx.hi[1] + pad : bx.lo[1] - pad,
+                                 (k & 4) ? bx.hi[2] + pad : bx.lo[2] - pad};
             double *w = &ctx->node_box[((size_t)n * 8 + k) * 3];
             for (int j = 0; j < 3; ++j) {
                 w[j] = q[0] * nodes[n].m[0 + j] + q[1] * nodes[n].m[3 + j] + q[2] * nodes[n].m[6 + j] + nodes[n].off[j];
