@@ -159,6 +159,10 @@ struct Ctx {
     int lane;
     uint32_t primary_mask; /* bit n clear: no primary ray of this tile can reach node n (wave-uniform) */
     uint32_t shadow_mask0; /* same for the tile's shadow rays towards light 0 (further lights: shadow_cull_mask) */
+    /* the ground plane (RenderParams::ground_node) is the ONLY node left in shadow_mask0: the tile's
+     * shadow rays towards light 0 are decided by plane_points_away alone, without building a ray */
+    bool shadow_ground_only;
+    double ground_y;
 };
 
 /* A ray in some object space: origin, unit direction and A = |d|^2 exactly as
@@ -749,9 +753,15 @@ DEV uint32_t shadow_cull_mask(const RenderParams &P, int lane, uint32_t l)
 
 /* Scene.testVisibility — rt/scene.d:62-78 */
 template <int LEVELS, bool PO>
-DEV bool test_visibility(const Ctx &cx, D3 from, D3 to, uint32_t node_mask)
+DEV bool test_visibility(const Ctx &cx, D3 from, D3 to, uint32_t node_mask, bool ground_only)
 {
     const D3 raw = to - from;
+    if (!PO && ground_only) { /* wave-uniform */
+        /* plane_points_away for the ground plane (identity matrix, zero offset) */
+        const bool sane = (fabs(raw.x) < 1e150) & (fabs(raw.z) < 1e150);
+        const bool up = (raw.y > 1e-150) & (raw.y < 1e150), down = (raw.y < -1e-150) & (raw.y > -1e150);
+        if (__all(sane & (((from.y > cx.ground_y) & up) | ((from.y < cx.ground_y) & down)))) return true;
+    }
     const uint32_t nn = cx.n_nodes;
     uint32_t n = next_node(node_mask, 0);
     if constexpr (PO) { /* every lane's ray provably leaves the leading planes behind: no ray needed yet */
@@ -881,7 +891,7 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const 
         if (L->lit) {
             const D3 lightPos = ld3(L->pos);
             shadow_rays += 1;
-            if (test_visibility<LEVELS, PO>(cx, h.p + N * 1e-6, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.lane, l) : 0xFFFFFFFFu))) {
+            if (test_visibility<LEVELS, PO>(cx, h.p + N * 1e-6, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.lane, l) : 0xFFFFFFFFu), l == 0 && cx.shadow_ground_only)) {
                 const F3 lightColor = ldf3(L->color);
                 const D3 lightDir = normalized(lightPos - h.p);
                 const double cosTheta = dot(lightDir, N);
@@ -1093,6 +1103,7 @@ DEV void render_body(const RenderParams &P)
      * ballot makes the wave-uniform masks — before any lane leaves, so that every
      * node has its lane. */
     uint32_t pmask = 0xFFFFFFFFu, smask0 = 0xFFFFFFFFu;
+    bool ground_only = false;
     if constexpr (!DOF) {
         if (P.n_cull) {
             int tx0, ty0, ty1;
@@ -1129,6 +1140,7 @@ DEV void render_body(const RenderParams &P)
                 const double *sr = P.shadow_rects + 4 * (mine ? lane : 0);
                 const bool apart = (sr[1] < fx0 - padx) | (sr[0] > fx1 + padx) | (sr[3] < fz0 - padz) | (sr[2] > fz1 + padz);
                 smask0 &= ~(uint32_t)__ballot(ok & mine & apart);
+                ground_only = (smask0 & (0xFFFFFFFFu >> (32u - nn))) == (1u << gnode);
             }
         }
     }
@@ -1153,6 +1165,8 @@ DEV void render_body(const RenderParams &P)
     cx.lane = lane;
     cx.primary_mask = pmask;
     cx.shadow_mask0 = smask0;
+    cx.shadow_ground_only = ground_only;
+    cx.ground_y = P.ground_y;
     Counters cnt = {0, 0};
     /* prepassOnly (rt/renderer.d:110-130): the pixel shows the sample of the
      * top-left pixel of its 16x16 block inside its bucket */
@@ -1224,6 +1238,8 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.lane = 0;
     cx.primary_mask = 0xFFFFFFFFu;
     cx.shadow_mask0 = 0xFFFFFFFFu;
+    cx.shadow_ground_only = false;
+    cx.ground_y = 0;
     Counters cnt = {0, 0};
     const uint64_t pixel = (uint64_t)P.probe_y * P.width + (uint64_t)P.probe_x;
     const F3 c = render_sample<LEVELS, DOF, false, false>(P, cx, (double)P.probe_x, (double)P.probe_y, pixel, 0, cnt, P.probe_out);
