@@ -597,3 +597,23 @@ def test_ground_plane_shadow_rectangles(gpu_ctx, tmp_path, scenes_dir):
         assert (pr, sh) == (st["primary"], st["shadow"]), seed
         differing += nne
     print("ground fuzz: %d differing floats over 80 scenes" % differing)
+
+
+def test_headline_config_full_frame(gpu_ctx):
+    """The bench workload itself — lecture5.sdl, 3840x2160, the reference's 5-tap AA — float for
+    float against the oracle (all host cores; a few seconds)."""
+    s = c2.parseSceneFromFile(os.path.join(SCENES, "lecture5.sdl"))
+    s.setFrameSize(3840, 2160)
+    s.setAA(True)
+    cam = s.beginFrame()
+    opts = s.renderOpts(count_rays=1)
+    assert opts.taps == 5
+    gpu_ctx.uploadScene(s.desc)
+    gpu = gpu_ctx.renderFrame(cam, opts)
+    primary, shadow = gpu_ctx.rayStats()
+    st = {}
+    ref = orc.render_frame(s.desc, cam, opts, 0, st)
+    md, nbad, nne = maxdiff(gpu, ref)
+    print("lecture5 4K x5: max|d|=%.3g, !=: %d of %d floats" % (md, nne, gpu.size))
+    assert md <= TOL and nbad == 0
+    assert (primary, shadow) == (st["primary"], st["shadow"]) == (41472000, 41472000)
