@@ -300,6 +300,7 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
     p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
     p.blocks_x = (p.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     p.seed = o->seed;
+    p.row_group_start = 0;
     p.planes_only = ctx->planes_only;
     p.ground_node = ctx->ground_node;
     p.ground_y = ctx->ground_y;
@@ -313,6 +314,18 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
         for (uint32_t n = 0; n < p.n_cull; ++n) {
             if (ctx->node_boxed[n]) cull_rect_of(cam, &ctx->node_box[(size_t)n * 24], p.cull_rect[n]);
             else { p.cull_rect[n][0] = p.cull_rect[n][1] = INT32_MIN; p.cull_rect[n][2] = p.cull_rect[n][3] = INT32_MAX; }
+        }
+        /* dispatch order: start at the tile rows where the boxed nodes begin (their tiles are the
+         * expensive ones), wrap around to the rows above them (mostly sky) at the end */
+        int32_t top = INT32_MAX;
+        for (uint32_t n = 0; n < p.n_cull; ++n)
+            if (ctx->node_boxed[n] && p.cull_rect[n][1] < top) top = p.cull_rect[n][1];
+        if (top != INT32_MAX && top > 0 && (uint32_t)top < o->height) {
+            /* frame row -> local row of this launch (strips: rows are dealt round-robin) */
+            const uint32_t local = (uint32_t)top / p.strip_world;
+            const uint32_t groups = (p.tiles_y + 7u) / 8u;
+            const uint32_t g = local / (kTileH * 8u);
+            p.row_group_start = g < groups ? g : 0;
         }
         if (p.n_cull) {
             p.n_cull_lights = ctx->n_lights < (uint32_t)kMaxCullLights ? ctx->n_lights : (uint32_t)kMaxCullLights;
@@ -851,6 +864,7 @@ int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
         p.row_offset = off;
         p.local_rows = rows - off < chunk ? rows - off : chunk;
         p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
+        if (chunk < rows) p.row_group_start = 0; /* the rotation is relative to the whole frame's rows */
         const int e = launch_render(p, variant, ctx->stream);
         if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
         HIP_TRY(ctx, hipEventRecord(ctx->chunk_done[n_chunks], ctx->stream));

@@ -174,6 +174,7 @@ struct RenderParams {
     const double *shadow_rects;    /* [kMaxCullNodes][4], device memory (scene constant) */
     uint32_t tiles_x, tiles_y;     /* tile grid over the LOCAL rows */
     uint32_t blocks_x;             /* ceil(tiles_x / kWavesPerBlock) */
+    uint32_t row_group_start;      /* first group of 8 tile rows to dispatch (< ceil(tiles_y / 8)) */
     uint64_t seed;
     float *out;                    /* local_rows * width * 3 floats */
     unsigned long long *ray_counters; /* [2] primary, shadow (nullable) */

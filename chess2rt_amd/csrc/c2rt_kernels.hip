@@ -693,7 +693,12 @@ DEV void tile_bounds(const RenderParams &P, int &tx0, int &ty0, int &ty1)
     const uint32_t b = blockIdx.x;
 #if C2RT_XCD_SWIZZLE
     const uint32_t xcd = b & 7u, j = b >> 3;
-    const uint32_t trow = (j / P.blocks_x) * 8u + xcd, bcol = j % P.blocks_x;
+    /* row groups are walked starting at P.row_group_start (where the boxed nodes begin on screen):
+     * the expensive tiles are dispatched first and the launch ends on cheap ones */
+    const uint32_t groups = (P.tiles_y + 7u) / 8u;
+    uint32_t grp = j / P.blocks_x + P.row_group_start;
+    if (grp >= groups) grp -= groups;
+    const uint32_t trow = grp * 8u + xcd, bcol = j % P.blocks_x;
 #else
     const uint32_t trow = b / P.blocks_x, bcol = b % P.blocks_x;
 #endif
@@ -1091,7 +1096,12 @@ DEV void render_body(const RenderParams &P)
     const uint32_t b = blockIdx.x;
 #if C2RT_XCD_SWIZZLE
     const uint32_t xcd = b & 7u, j = b >> 3;
-    const uint32_t trow = (j / P.blocks_x) * 8u + xcd, bcol = j % P.blocks_x;
+    /* row groups are walked starting at P.row_group_start (where the boxed nodes begin on screen):
+     * the expensive tiles are dispatched first and the launch ends on cheap ones */
+    const uint32_t groups = (P.tiles_y + 7u) / 8u;
+    uint32_t grp = j / P.blocks_x + P.row_group_start;
+    if (grp >= groups) grp -= groups;
+    const uint32_t trow = grp * 8u + xcd, bcol = j % P.blocks_x;
 #else
     const uint32_t trow = b / P.blocks_x, bcol = b % P.blocks_x;
 #endif
