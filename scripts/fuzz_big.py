@@ -6,7 +6,9 @@ from scene_fuzz import random_scene_sdl
 d='/tmp/fz'; os.makedirs(d, exist_ok=True); shutil.copy(ROOT+'/tests/golden/scenes/floor.bmp', d+'/floor.bmp')
 ctx=c2.Context(0); worst=0; bad=0; nne=0
 from scene_fuzz import many_lights_scene_sdl
-for seed in range(1000, 2500):
+START = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+COUNT = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+for seed in range(START, START + COUNT):
     open(d+"/f.sdl","w").write(many_lights_scene_sdl(seed) if seed % 5 == 0 else random_scene_sdl(seed, max_depth=4 if seed%2 else 3))
     s=c2.parseSceneFromFile(d+'/f.sdl'); s.setFrameSize(64,48); cam=s.beginFrame(); opts=s.renderOpts(count_rays=1)
     ctx.uploadScene(s.desc); a=ctx.renderFrame(cam,opts); pr,sh=ctx.rayStats(); st={}

@@ -7,7 +7,8 @@ from scene_fuzz import ground_scene_sdl
 d = '/tmp/fzg'; os.makedirs(d, exist_ok=True); shutil.copy(ROOT + '/tests/golden/scenes/floor.bmp', d + '/floor.bmp')
 ctx = c2.Context(0); bad = 0; nne = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-for seed in range(1000, 1000 + N):
+START = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+for seed in range(START, START + N):
     open(d + "/f.sdl", "w").write(ground_scene_sdl(seed))
     s = c2.parseSceneFromFile(d + '/f.sdl')
     s.setFrameSize(*( (96, 72) if seed % 2 else (160, 120) )); cam = s.beginFrame(); opts = s.renderOpts(count_rays=1)

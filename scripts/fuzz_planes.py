@@ -6,7 +6,8 @@ import chess2rt_amd as c2, oracle_lib as orc
 from scene_fuzz import planes_scene_sdl
 d = '/tmp/fzp'; os.makedirs(d, exist_ok=True); shutil.copy(ROOT + '/tests/golden/scenes/floor.bmp', d + '/floor.bmp')
 ctx = c2.Context(0); bad = 0; nne = 0
-for seed in range(1000, 1000 + int(sys.argv[1]) if len(sys.argv) > 1 else 2000):
+START = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+for seed in range(START, START + (int(sys.argv[1]) if len(sys.argv) > 1 else 1000)):
     open(d + "/f.sdl", "w").write(planes_scene_sdl(seed))
     s = c2.parseSceneFromFile(d + '/f.sdl'); s.setFrameSize(64, 48); cam = s.beginFrame(); opts = s.renderOpts(count_rays=1)
     ctx.uploadScene(s.desc); a = ctx.renderFrame(cam, opts); pr, sh = ctx.rayStats(); st = {}
