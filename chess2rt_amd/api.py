@@ -198,6 +198,13 @@ class Context:
         self._check(self._lib.c2rt_render_frame_rgb32(self._h, C.byref(cam), C.byref(opts), out.ctypes.data_as(C.c_void_p), stop))
         return out
 
+    def renderFrameRGB32Into(self, cam, opts, out, stop_flag=None):
+        """Same into a caller-owned (local_rows, W) uint32 array (pin it with pinHostBuffer for overlapped copies)."""
+        assert out.dtype == np.uint32 and out.flags["C_CONTIGUOUS"] and out.size == self.localRows(opts) * opts.width
+        stop = stop_flag.ctypes.data_as(C.c_void_p) if stop_flag is not None else None
+        self._check(self._lib.c2rt_render_frame_rgb32(self._h, C.byref(cam), C.byref(opts), out.ctypes.data_as(C.c_void_p), stop))
+        return out
+
     def deinterleaveStripsRGB32(self, gathered_ptr, frame_ptr, width, height, strip_height, world, stream=0):
         self._check(self._lib.c2rt_deinterleave_strips_rgb32(self._h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), width, height,
                                                              strip_height, world, C.c_void_p(stream)))

@@ -801,6 +801,72 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
     return C2RT_OK;
 }
 
+/* Host-output frames (c2rt_render_frame: float RGB; c2rt_render_frame_rgb32: Color.toRGB32 words).
+ * Into a buffer page-locked with c2rt_pin_host_buffer the frame is rendered in up to 8 row chunks:
+ * chunk i streams back over PCIe (copy stream) while chunk i+1 renders (and is encoded), and the
+ * stop flag is polled between chunks (finer than the reference's between-pass polling).  Into
+ * pageable memory: one launch, one copy — chunked copies into pageable memory are slower than one
+ * (measured).  ctx->frame holds the float rows, followed by the packed rows for the RGB32 form. */
+static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_rgb,
+                          uint32_t *out_rgb32, const volatile uint8_t *stop_flag)
+{
+    RenderParams p;
+    fill_params(ctx, cam, opts, p);
+    p.out = ctx->frame;
+    ctx->counters_valid = false;
+    if (opts->count_rays) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        p.ray_counters = ctx->counters;
+    }
+    const uint32_t rows = p.local_rows;
+    const size_t row_px = opts->width, row_floats = row_px * 3;
+    uint32_t *packed = reinterpret_cast<uint32_t *>(ctx->frame + (size_t)rows * row_floats);
+    char *dst = out_rgb ? reinterpret_cast<char *>(out_rgb) : reinterpret_cast<char *>(out_rgb32);
+    const size_t dst_row_bytes = out_rgb ? row_floats * sizeof(float) : row_px * sizeof(uint32_t);
+    bool is_pinned = false;
+    for (const auto &pb : ctx->pinned)
+        is_pinned = is_pinned || (dst >= reinterpret_cast<char *>(pb.first) &&
+                                  dst + (size_t)rows * dst_row_bytes <= reinterpret_cast<char *>(pb.first) + pb.second);
+    /* one chunk per ~8 MB crossing PCIe, at most 8: enough copies in flight to hide them behind the
+     * kernels, few enough launches that their tails do not add up (measured on 4K frames: 8 chunks for
+     * the 99.5 MB float frame, 4 for the 33 MB RGB32 one) */
+    const size_t total_bytes = (size_t)rows * dst_row_bytes;
+    uint32_t want = (uint32_t)((total_bytes + (8u << 20) - 1) / (8u << 20));
+    if (want < 1) want = 1;
+    if (want > (uint32_t)kMaxChunks) want = kMaxChunks;
+    uint32_t chunk = is_pinned ? ((rows + want - 1) / want + kTileH - 1) / kTileH * kTileH : rows;
+    if (chunk < 64) chunk = 64;
+    const KernelVariant variant = variant_of(ctx, cam);
+    bool cancelled = false;
+    int n_chunks = 0;
+    for (uint32_t off = 0; off < rows && n_chunks < kMaxChunks; off += chunk, ++n_chunks) {
+        if (stop_flag && *stop_flag) { cancelled = true; break; }
+        p.row_offset = off;
+        p.local_rows = rows - off < chunk ? rows - off : chunk;
+        p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
+        if (chunk < rows) p.row_group_start = 0; /* the rotation is relative to the whole frame's rows */
+        int e = launch_render(p, variant, ctx->stream);
+        if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
+        const void *src = ctx->frame + off * row_floats;
+        if (out_rgb32) {
+            e = launch_encode_rgb32(ctx->frame + off * row_floats, packed + off * row_px, (uint64_t)p.local_rows * row_px, ctx->srgb_lut, ctx->stream);
+            if (e != 0) return fail(ctx, C2RT_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
+            src = packed + off * row_px;
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->chunk_done[n_chunks], ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_done[n_chunks], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(dst + off * dst_row_bytes, src, (size_t)p.local_rows * dst_row_bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (cancelled) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested during the frame");
+    if (opts->count_rays) {
+        ctx->counters_valid = true;
+        ctx->counters_stream = ctx->stream;
+    }
+    return C2RT_OK;
+}
+
 uint32_t c2rt_local_rows(const c2rt_render_opts *opts)
 {
     if (!opts) return 0;
@@ -833,53 +899,7 @@ int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->frame), floats * sizeof(float)));
         ctx->frame_floats = floats;
     }
-    /* Into a pinned buffer the frame is rendered in up to 8 row chunks: chunk i
-     * streams back over PCIe (copy stream) while chunk i+1 renders, and the
-     * stop flag is polled between chunks (finer than the reference's
-     * between-pass polling).  Into pageable memory: one launch, one copy. */
-    RenderParams p;
-    fill_params(ctx, cam, opts, p);
-    p.out = ctx->frame;
-    ctx->counters_valid = false;
-    if (opts->count_rays) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
-        p.ray_counters = ctx->counters;
-    }
-    const uint32_t rows = p.local_rows;
-    /* chunking only pays when the copies are truly asynchronous, i.e. the
-     * destination was page-locked with c2rt_pin_host_buffer (measured: chunked
-     * copies into pageable memory are slower than one copy) */
-    bool is_pinned = false;
-    for (const auto &pb : ctx->pinned)
-        is_pinned = is_pinned || (out_rgb >= pb.first && reinterpret_cast<char *>(out_rgb) + floats * sizeof(float) <=
-                                                             reinterpret_cast<char *>(pb.first) + pb.second);
-    uint32_t chunk = is_pinned ? ((rows + 7) / 8 + kTileH - 1) / kTileH * kTileH : rows;
-    if (chunk < 64) chunk = 64;
-    const KernelVariant variant = variant_of(ctx, cam);
-    const size_t row_floats = (size_t)opts->width * 3;
-    bool cancelled = false;
-    int n_chunks = 0;
-    for (uint32_t off = 0; off < rows && n_chunks < kMaxChunks; off += chunk, ++n_chunks) {
-        if (stop_flag && *stop_flag) { cancelled = true; break; }
-        p.row_offset = off;
-        p.local_rows = rows - off < chunk ? rows - off : chunk;
-        p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
-        if (chunk < rows) p.row_group_start = 0; /* the rotation is relative to the whole frame's rows */
-        const int e = launch_render(p, variant, ctx->stream);
-        if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
-        HIP_TRY(ctx, hipEventRecord(ctx->chunk_done[n_chunks], ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_done[n_chunks], 0));
-        HIP_TRY(ctx, hipMemcpyAsync(out_rgb + off * row_floats, ctx->frame + off * row_floats,
-                                    (size_t)p.local_rows * row_floats * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
-    }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (cancelled) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested during the frame");
-    if (opts->count_rays) {
-        ctx->counters_valid = true;
-        ctx->counters_stream = ctx->stream;
-    }
-    return C2RT_OK;
+    return render_to_host(ctx, cam, opts, out_rgb, nullptr, stop_flag);
 }
 
 int c2rt_pin_host_buffer(c2rt_ctx *ctx, float *out_rgb, size_t bytes)
@@ -992,16 +1012,7 @@ int c2rt_render_frame_rgb32(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->frame), floats * sizeof(float)));
         ctx->frame_floats = floats;
     }
-    uint32_t *packed = reinterpret_cast<uint32_t *>(ctx->frame + pixels * 3);
-    st = render_device(ctx, cam, opts, ctx->frame, ctx->stream);
-    if (st != C2RT_OK) return st;
-    if (pixels) {
-        const int e = launch_encode_rgb32(ctx->frame, packed, pixels, ctx->srgb_lut, ctx->stream);
-        if (e != 0) return fail(ctx, C2RT_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
-        HIP_TRY(ctx, hipMemcpyAsync(out_rgb32, packed, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return C2RT_OK;
+    return render_to_host(ctx, cam, opts, nullptr, out_rgb32, stop_flag);
 }
 
 int c2rt_encode_rgb32(c2rt_ctx *ctx, const float *frame_dev, uint32_t *out_dev, uint64_t n_pixels, void *hip_stream)

@@ -26,3 +26,18 @@ for (w, h, taps) in [(3840, 2160, 5), (3840, 2160, 1), (1920, 1080, 1)]:
     dt = (time.perf_counter() - t) / n
     ctx.unpinHostBuffer(out)
     print("    same into a buffer pinned with c2rt_pin_host_buffer: %.3f ms/frame, %.0f Mray/s" % (dt * 1e3, (pr + sh) / dt / 1e6))
+    out32 = np.empty((h, w), np.uint32)
+    ctx.renderFrameRGB32Into(cam, opts, out32)
+    t = time.perf_counter()
+    for _ in range(n):
+        ctx.renderFrameRGB32Into(cam, opts, out32)
+    dt = (time.perf_counter() - t) / n
+    print("    RGB32 (Color.toRGB32 on the GPU, %.1f MB over PCIe) into pageable memory: %.3f ms/frame" % (w * h * 4 / 1e6, dt * 1e3))
+    ctx.pinHostBuffer(out32)
+    ctx.renderFrameRGB32Into(cam, opts, out32)
+    t = time.perf_counter()
+    for _ in range(n):
+        ctx.renderFrameRGB32Into(cam, opts, out32)
+    dt = (time.perf_counter() - t) / n
+    ctx.unpinHostBuffer(out32)
+    print("    RGB32 into a pinned buffer (row chunks, copies overlapped): %.3f ms/frame, %.0f Mray/s" % (dt * 1e3, (pr + sh) / dt / 1e6))

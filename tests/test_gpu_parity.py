@@ -510,6 +510,20 @@ def test_rgb32_frame_and_strips(gpu_ctx):
     gpu_ctx.deinterleaveStripsRGB32(gathered.data_ptr(), frame.data_ptr(), W, H, 8, world, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(frame.cpu().numpy().astype(np.uint32), packed)
+    # pinned destination: the frame comes back in row chunks (render + encode of chunk i+1 overlap the copy of chunk i)
+    scene.setFrameSize(1283, 1001)
+    cam2 = scene.beginFrame()
+    o2 = scene.renderOpts(taps=1, count_rays=1)
+    whole = gpu_ctx.renderFrameRGB32(cam2, o2)
+    pr = gpu_ctx.rayStats()
+    pinned = np.zeros((1001, 1283), np.uint32)
+    gpu_ctx.pinHostBuffer(pinned)
+    try:
+        gpu_ctx.renderFrameRGB32Into(cam2, o2, pinned)
+        assert gpu_ctx.rayStats() == pr
+    finally:
+        gpu_ctx.unpinHostBuffer(pinned)
+    assert np.array_equal(pinned, whole)
 
 
 def test_plain_c_caller_matches_oracle(tmp_path):
