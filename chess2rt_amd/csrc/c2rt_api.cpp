@@ -260,8 +260,7 @@ int check_frame_args(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_ren
         return fail(ctx, C2RT_ERR_INVALID_ARG, "strip_rank %u >= strip_world %u", o->strip_rank, o->strip_world);
     if (cam->dof && (cam->num_samples == 0 || cam->num_samples > 4096))
         return fail(ctx, C2RT_ERR_LIMIT, "dof numSamples %u outside 1..4096", cam->num_samples);
-    if (o->prepass_bucket && (cam->dof || o->prepass_bucket > 65536))
-        return fail(ctx, C2RT_ERR_UNSUPPORTED, "prepassOnly with depth of field (block-sized jitter) is not supported");
+    if (o->prepass_bucket > 65536) return fail(ctx, C2RT_ERR_UNSUPPORTED, "prepass bucket size %u > 65536", o->prepass_bucket);
     if (!(cam->frame_width > 0) || !(cam->frame_height > 0))
         return fail(ctx, C2RT_ERR_INVALID_ARG, "camera frame size must be positive");
     return C2RT_OK;

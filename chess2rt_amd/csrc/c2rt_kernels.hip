@@ -1032,7 +1032,7 @@ DEV F3 combine_stereo(F3 l, F3 r)
 
 /* renderSample — rt/renderer.d:254-313 */
 template <int LEVELS, bool DOF, bool MLC, bool PO>
-DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, uint64_t pixel, uint32_t tap,
+DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, int dx, int dy, uint64_t pixel, uint32_t tap,
                      Counters &cnt, c2rt_trace_result *probe)
 {
     Rng rng = {P.seed, pixel, tap, 0, 0};
@@ -1057,8 +1057,8 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, u
                 double sx = x, sy = y;
                 if (dof) {
                     const double jx = rng_next(rng), jy = rng_next(rng);
-                    sx = x + jx * 1;
-                    sy = y + jy * 1;
+                    sx = x + jx * dx;
+                    sy = y + jy * dy;
                 }
                 screen_ray<true>(P, sx, sy, stereo ? (e == 0 ? -1 : +1) : 0, rng, o, d);
                 const F3 c = raytrace<LEVELS, MLC, PO>(P, cx, o, d, cnt, e == 0 ? probe : nullptr);
@@ -1181,11 +1181,16 @@ DEV void render_body(const RenderParams &P)
     /* prepassOnly (rt/renderer.d:110-130): the pixel shows the sample of the
      * top-left pixel of its 16x16 block inside its bucket */
     uint32_t sx = x, sy = y;
+    int jdx = 1, jdy = 1; /* renderPixelNoAA's dx, dy: the extent depth-of-field jitter spans */
     if (P.prepass_bucket) {
         const uint32_t bs = P.prepass_bucket;
         const uint32_t bx = x / bs * bs, by = y / bs * bs;
         sx = bx + ((x - bx) & ~15u);
         sy = by + ((y - by) & ~15u);
+        /* the 16x16 block is clipped by its bucket, the bucket by the frame (rt/renderer.d:113-119, 208) */
+        const uint32_t bx1 = bx + bs < P.width ? bx + bs : P.width, by1 = by + bs < P.height ? by + bs : P.height;
+        jdx = (int)(sx + 16u < bx1 ? 16u : bx1 - sx);
+        jdy = (int)(sy + 16u < by1 ? 16u : by1 - sy);
     }
     const uint64_t pixel = (uint64_t)sy * P.width + sx;
     const uint32_t ntaps = P.taps;
@@ -1196,7 +1201,7 @@ DEV void render_body(const RenderParams &P)
     F3 accum = mkf(0, 0, 0);
 #pragma unroll 1
     for (uint32_t s = 0; s < ntaps; ++s) {
-        const F3 c = render_sample<LEVELS, DOF, MLC, PO>(P, cx, (double)sx + k_aa_x[s], (double)sy + k_aa_y[s], pixel, s, cnt, nullptr);
+        const F3 c = render_sample<LEVELS, DOF, MLC, PO>(P, cx, (double)sx + k_aa_x[s], (double)sy + k_aa_y[s], jdx, jdy, pixel, s, cnt, nullptr);
         accum = s == 0 ? c : accum + c;
     }
     if (ntaps > 1) accum = accum / (float)ntaps; /* `accum / 5`: Color / float */
@@ -1252,7 +1257,7 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.ground_y = 0;
     Counters cnt = {0, 0};
     const uint64_t pixel = (uint64_t)P.probe_y * P.width + (uint64_t)P.probe_x;
-    const F3 c = render_sample<LEVELS, DOF, false, false>(P, cx, (double)P.probe_x, (double)P.probe_y, pixel, 0, cnt, P.probe_out);
+    const F3 c = render_sample<LEVELS, DOF, false, false>(P, cx, (double)P.probe_x, (double)P.probe_y, 1, 1, pixel, 0, cnt, P.probe_out);
     P.probe_out->color[0] = c.r;
     P.probe_out->color[1] = c.g;
     P.probe_out->color[2] = c.b;

@@ -190,8 +190,9 @@ typedef struct c2rt_render_opts {
     uint32_t count_rays;           /* 1: also count primary/shadow rays cast */
     /* 0: the normal frame.  N > 0: `prepassOnly` (rt/renderer.d:110-130) with
      * bucketSize N: every 16x16 block of every NxN bucket is filled with the one
-     * sample taken at its top-left pixel; taps are ignored (the reference
-     * returns before the AA pass). */
+     * sample taken at its top-left pixel (with depth of field its jitter spans
+     * the clipped block, rt/renderer.d:119,277); taps are ignored (the
+     * reference returns before the AA pass). */
     uint32_t prepass_bucket;
 } c2rt_render_opts;
 

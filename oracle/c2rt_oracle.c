@@ -845,7 +845,7 @@ typedef struct {
 } RenderCtx;
 
 /* renderSampleDefault / renderSampleDof — rt/renderer.d:270-287,303-313 */
-static Col render_sample(const RenderCtx *rc, double x, double y, uint64_t pixel, uint32_t tap,
+static Col render_sample(const RenderCtx *rc, double x, double y, int dx, int dy, uint64_t pixel, uint32_t tap,
                          Counters *cnt, TraceResult *tr)
 {
     const c2rt_camera_frame *cam = rc->cam;
@@ -857,12 +857,12 @@ static Col render_sample(const RenderCtx *rc, double x, double y, uint64_t pixel
             rng.dim = 0;
             if (cam->stereo_separation == 0) {
                 double jx = rng_next(&rng), jy = rng_next(&rng);
-                average = cadd(average, raytrace(rc->scene, screen_ray(cam, x + jx * 1, y + jy * 1, 0, &rng), cnt, tr));
+                average = cadd(average, raytrace(rc->scene, screen_ray(cam, x + jx * dx, y + jy * dy, 0, &rng), cnt, tr));
             } else {
                 double jx = rng_next(&rng), jy = rng_next(&rng);
-                Col l = raytrace(rc->scene, screen_ray(cam, x + jx * 1, y + jy * 1, -1, &rng), cnt, tr);
+                Col l = raytrace(rc->scene, screen_ray(cam, x + jx * dx, y + jy * dy, -1, &rng), cnt, tr);
                 jx = rng_next(&rng), jy = rng_next(&rng);
-                Col r = raytrace(rc->scene, screen_ray(cam, x + jx * 1, y + jy * 1, +1, &rng), cnt, NULL);
+                Col r = raytrace(rc->scene, screen_ray(cam, x + jx * dx, y + jy * dy, +1, &rng), cnt, NULL);
                 average = cadd(average, combine_stereo(l, r));
             }
         }
@@ -921,13 +921,13 @@ static void *worker(void *arg)
                 uint64_t pixel = (uint64_t)y * W + (uint64_t)x;
                 float *px = row + 3 * (size_t)x;
                 if (job->pass == 2) {
-                    Col c = render_sample(&job->rc, x, y, pixel, 0, &cnt, NULL);
+                    Col c = render_sample(&job->rc, x, y, 1, 1, pixel, 0, &cnt, NULL);
                     px[0] = c.r, px[1] = c.g, px[2] = c.b;
                 } else {
                     Col accum = colp(px);
                     for (uint32_t sample = 1; sample < ntaps; ++sample)
                         accum = cadd(accum, render_sample(&job->rc, x + k_aa_kernel[sample][0],
-                                                          y + k_aa_kernel[sample][1], pixel, sample, &cnt, NULL));
+                                                          y + k_aa_kernel[sample][1], 1, 1, pixel, sample, &cnt, NULL));
                     Col c = cdivf(accum, (float)ntaps); /* `accum / 5`: float division */
                     px[0] = c.r, px[1] = c.g, px[2] = c.b;
                 }
@@ -974,7 +974,7 @@ static int check_args(Scene *s, const c2rt_camera_frame *cam, const c2rt_render_
     if (o->width == 0 || o->height == 0) return C2RT_ERR_INVALID_ARG;
     if (o->taps != C2RT_TAPS_1 && o->taps != C2RT_TAPS_REF5 && o->taps != C2RT_TAPS_4) return C2RT_ERR_INVALID_ARG;
     if (o->strip_world > 1 && o->strip_rank >= o->strip_world) return C2RT_ERR_INVALID_ARG;
-    if (o->prepass_bucket && (cam->dof || o->prepass_bucket > 65536)) return C2RT_ERR_UNSUPPORTED;
+    if (o->prepass_bucket > 65536) return C2RT_ERR_UNSUPPORTED;
     return C2RT_OK;
 }
 
@@ -1013,7 +1013,8 @@ int orc_render_frame(const c2rt_scene_desc *scene, const c2rt_camera_frame *cam,
                     for (int dx = 0; dx < bw; dx += 16) {
                         const int ex = dx + 16 < bw ? dx + 16 : bw;
                         const int x0 = bx + dx, y0 = by + dy;
-                        Col c = render_sample(&job.rc, x0, y0, (uint64_t)y0 * W + (uint64_t)x0, 0, &cnt, NULL);
+                        /* renderPixelNoAA(x, y, ex - dx, ey - dy): depth-of-field jitter spans the block */
+                        Col c = render_sample(&job.rc, x0, y0, ex - dx, ey - dy, (uint64_t)y0 * W + (uint64_t)x0, 0, &cnt, NULL);
                         for (int y = y0; y < by + ey; ++y) {
                             if (!row_is_local(opts, (uint32_t)y)) continue;
                             float *row = out_rgb + 3 * (size_t)local_row(opts, (uint32_t)y) * W;
@@ -1056,7 +1057,7 @@ int orc_render_pixel(const c2rt_scene_desc *scene, const c2rt_camera_frame *cam,
     RenderCtx rc = {scene, cam, opts};
     TraceResult tr;
     memset(&tr, 0, sizeof tr);
-    Col c = render_sample(&rc, x, y, (uint64_t)y * opts->width + (uint64_t)x, 0, NULL, &tr);
+    Col c = render_sample(&rc, x, y, 1, 1, (uint64_t)y * opts->width + (uint64_t)x, 0, NULL, &tr);
     out->color[0] = c.r, out->color[1] = c.g, out->color[2] = c.b;
     out->closest_node = tr.closestNode;
     out->leaf_geom = tr.closestNode >= 0 ? tr.data.g : -1;

@@ -424,6 +424,18 @@ def test_prepass_only_preview(gpu_ctx, tmp_path):
         a = gpu_ctx.renderFrame(cam, po)
         ref = orc.render_frame(scene.desc, cam, po, 0)
         assert maxdiff(a, ref)[0] <= TOL
+    # with depth of field the lens jitter spans the (clipped) 16x16 block: renderPixelNoAA(x, y, ex - dx, ey - dy)
+    zs, zcam, _ = load_config("zaphod_215x143_dof25")
+    gpu_ctx.uploadScene(zs.desc)
+    for bucket in (48, 40):
+        _, _, po = load_config("zaphod_215x143_dof25", prepass_bucket=bucket, count_rays=1)
+        a = gpu_ctx.renderFrame(zcam, po)
+        pr = gpu_ctx.rayStats()
+        st = {}
+        ref = orc.render_frame(zs.desc, zcam, po, 0, st)
+        assert maxdiff(a, ref)[0] <= TOL
+        assert len(np.unique(a.reshape(-1, 3), axis=0)) > 20          # block colours, not one flat value
+    gpu_ctx.uploadScene(scene.desc)
     # through the host mirror: GlobalSettings.prepassOnly
     text = open(os.path.join(SCENES, "lecture4.sdl")).read().replace("frameHeight\t\t\t480", "frameHeight 480\n        prepassOnly true")
     assert "prepassOnly" in text
