@@ -650,6 +650,8 @@ int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         }
     }
 
+    if (levels > 0 && s->n_geoms > C2RT_MAX_CSG_GEOMS)
+        return fail(ctx, C2RT_ERR_LIMIT, "%u geometries in a scene with CsgOps (limit %d)", s->n_geoms, C2RT_MAX_CSG_GEOMS);
     ctx->planes_only = s->n_nodes > 0;
     for (uint32_t n = 0; n < s->n_nodes; ++n) {
         DevNode &d = nodes[n];

@@ -34,8 +34,8 @@ constexpr int kMaxCullLights = C2RT_MAX_CULL_LIGHTS; /* lights beyond this get n
 #endif
 constexpr int kWavesPerBlock = C2RT_WAVES_PER_BLOCK; /* horizontally adjacent tiles per workgroup */
 constexpr int kBlockThreads = kWave * kWavesPerBlock;
-/* LDS bytes one wavefront needs per CSG nesting level: dist[16][64] + tag[16][64] */
-constexpr int kCsgLdsPerLevel = kCsgEntries * kWave * (8 + 4);
+/* LDS bytes one wavefront needs per CSG nesting level: dist[16][64] (8 B) + tag[16][64] (2 B) = 10 KiB */
+constexpr int kCsgLdsPerLevel = kCsgEntries * kWave * (8 + 2);
 
 enum GeomFlags : int32_t {
     kGeomBounded = 1,              /* `bound` is valid: a ray that misses it cannot hit */

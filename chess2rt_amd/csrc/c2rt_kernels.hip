@@ -14,7 +14,7 @@
  *   - CSG hit lists live in LDS, one [entry][lane] slab per nesting level
  *     (bank = lane, conflict-free for any per-lane entry index); only
  *     (dist, tag) is kept per hit and the winning hit is re-derived, which
- *     keeps the slab at 12 KiB per wave and level;
+ *     keeps the slab at 10 KiB per wave and level;
  *   - geometry is fp64 and colour fp32 in the reference's operation order
  *     (built with -ffp-contract=off), because checker edges, shadow
  *     terminators and CSG boundaries flip on 1-ulp differences.
@@ -49,7 +49,7 @@ __device__ __noinline__ double c2_cos(double a) { return cos(a); }
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(2, 2))) /* 198 VGPRs, no scratch */
 #elif defined(C2RT_UNIT) && C2RT_UNIT >= 3
 /* every nesting level keeps its stepping state live (all levels are inlined
- * once): ~255 VGPRs without scratch; the LDS slabs (12 KiB per level and wave)
+ * once): ~255 VGPRs without scratch; the LDS slabs (10 KiB per level and wave)
  * cap residency below one wave per SIMD anyway */
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
@@ -340,10 +340,14 @@ DEV bool geom_is_inside(const Ctx &cx, int gid, D3 p)
 template <int LEVEL, int NEED>
 __device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h, bool full);
 
+/* hit-list tag: leaf geometry (12 bits: C2RT_MAX_CSG_GEOMS) | child side | index of the hit in its child's list */
+static_assert(kMaxCsgHits <= 8 && C2RT_MAX_CSG_GEOMS <= 4096, "16-bit hit tags");
+DEV uint16_t csg_tag(int leaf, int side, int k) { return (uint16_t)(((uint32_t)leaf << 4) | ((uint32_t)side << 3) | (uint32_t)k); }
+
 /* CsgOp.intersect (+ CsgDiff.intersect) for a CSG whose subtree has at most
  * LEVEL nesting levels.  The hit lists of findAllIntersections
  * (rt/geometry.d:271-290) are kept in this level's LDS slab as
- * (dist, tag = leaf<<8 | side<<4 | k); they are concatenated left-then-right
+ * (dist, 16-bit tag = leaf<<4 | side<<3 | k); they are concatenated left-then-right
  * and shell-sorted exactly as util/array.d:95-111 does (same tie behaviour),
  * walked with the in/out toggles of rt/geometry.d:303-329 (including the
  * `current.g is left` leaf-identity test), and the winning hit is then
@@ -361,7 +365,7 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
 {
     static_assert(LEVEL >= 1, "CSG needs a slab");
     double *ldist = reinterpret_cast<double *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel) + cx.lane;
-    uint32_t *ltag = reinterpret_cast<uint32_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
+    uint16_t *ltag = reinterpret_cast<uint16_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
     const int type = G->type, left = G->left, right = G->right, flags = G->flags;
     const D3 d = ray.d;
     const bool want_full = NEED == kFull || (NEED == kRt && full);
@@ -389,7 +393,7 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
             rr.o = t.p + d * 1e-6;
             if (!replay) {
                 ldist[(n + k) * kWave] = t.dist;
-                ltag[(n + k) * kWave] = ((uint32_t)t.g << 8) | ((uint32_t)side << 4) | (uint32_t)k;
+                ltag[(n + k) * kWave] = csg_tag(t.g, side, k);
             }
             ++k;
         }
@@ -404,7 +408,7 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
         for (int inc = n / 2; inc;) {
             for (int i = 0; i < n; ++i) {
                 const double ed = ldist[i * kWave];
-                const uint32_t et = ltag[i * kWave];
+                const uint16_t et = ltag[i * kWave];
                 while (i >= inc && ldist[(i - inc) * kWave] > ed) {
                     ldist[i * kWave] = ldist[(i - inc) * kWave];
                     ltag[i * kWave] = ltag[(i - inc) * kWave];
@@ -419,7 +423,7 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
         int win = -1;
         for (int i = 0; i < n; ++i) {
             const uint32_t tag = ltag[i * kWave];
-            const bool isL = (int)(tag >> 8) == left;
+            const bool isL = (int)(tag >> 4) == left;
             inL ^= isL;
             inR ^= !isL;
             const bool in = type == C2RT_GEOM_CSG_UNION ? (inL | inR)
@@ -431,8 +435,8 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
         if (wdist > h.dist) return false;
         if (NEED == kBool) { h.dist = wdist; return true; }
         const uint32_t wtag = ltag[win * kWave];
-        wside = (wtag >> 4) & 1;
-        wk = wtag & 15;
+        wside = (wtag >> 3) & 1;
+        wk = wtag & 7;
     }
     h = t;
 
@@ -452,7 +456,7 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
 {
     constexpr int LEVEL = 1;
     double *ldist = reinterpret_cast<double *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel) + cx.lane;
-    uint32_t *ltag = reinterpret_cast<uint32_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
+    uint16_t *ltag = reinterpret_cast<uint16_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
     const int type = G->type, left = G->left, right = G->right, flags = G->flags;
     const D3 d = ray.d;
 
@@ -472,7 +476,7 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
             cur = t.dist;
             rr.o = t.p + d * 1e-6;
             ldist[(n + k) * kWave] = t.dist;
-            ltag[(n + k) * kWave] = ((uint32_t)t.g << 8) | ((uint32_t)side << 4) | (uint32_t)k;
+            ltag[(n + k) * kWave] = csg_tag(t.g, side, k);
             ++k;
         }
         if (side == 0) nL = k; else nR = k;
@@ -485,7 +489,7 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
     for (int inc = n / 2; inc;) {
         for (int i = 0; i < n; ++i) {
             const double ed = ldist[i * kWave];
-            const uint32_t et = ltag[i * kWave];
+            const uint16_t et = ltag[i * kWave];
             while (i >= inc && ldist[(i - inc) * kWave] > ed) {
                 ldist[i * kWave] = ldist[(i - inc) * kWave];
                 ltag[i * kWave] = ltag[(i - inc) * kWave];
@@ -501,7 +505,7 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
     int win = -1;
     for (int i = 0; i < n; ++i) {
         const uint32_t tag = ltag[i * kWave];
-        const bool isL = (int)(tag >> 8) == left;
+        const bool isL = (int)(tag >> 4) == left;
         inL ^= isL;
         inR ^= !isL;
         const bool in = type == C2RT_GEOM_CSG_UNION ? (inL | inR)
@@ -515,7 +519,7 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
 
     /* re-derive the winning IntersectionData (data = current, rt/geometry.d:326) */
     const uint32_t wtag = ltag[win * kWave];
-    const int wside = (wtag >> 4) & 1, wk = wtag & 15;
+    const int wside = (wtag >> 3) & 1, wk = wtag & 7;
     const int child = wside ? right : left;
     ORay rr = ray;
     double cur = 0;

@@ -36,6 +36,7 @@ extern "C" {
 
 /* hard limits of the device path (upload fails with C2RT_ERR_LIMIT beyond) */
 #define C2RT_MAX_CSG_DEPTH 4   /* nesting levels of CsgOp under a node       */
+#define C2RT_MAX_CSG_GEOMS 4096 /* geometries in a scene that has CsgOps (hit lists tag leaves in 12 bits) */
 #define C2RT_MAX_CSG_HITS 8    /* hits kept per CSG child per ray (the reference
                                   grows a MyArray, util/array.d:54-63; a sane
                                   primitive yields at most 2)                 */
