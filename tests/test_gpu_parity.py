@@ -272,6 +272,20 @@ def test_csg_depth_limit_and_cycles_are_rejected(gpu_ctx):
     with pytest.raises(c2.C2rtError) as e:
         gpu_ctx.uploadScene(d)
     assert e.value.status == _abi.ERR_INVALID_ARG
+    # hit lists tag their leaves in 12 bits: a scene WITH CsgOps may hold 4096 geometries, one without any number
+    big = 4097
+    types2 = (C.c_int32 * big)(*([_abi.GEOM_SPHERE] * (big - 1) + [_abi.GEOM_CSG_UNION]))
+    params2 = (C.c_double * (4 * big))(*([0, 0, 5, 1] * big))
+    ch2 = (C.c_int32 * (2 * big))(*([-1, -1] * (big - 1) + [0, 1]))
+    d.n_geoms, d.geom_type, d.geom_param, d.geom_child = big, types2, params2, ch2
+    ng[0] = big - 1
+    with pytest.raises(c2.C2rtError) as e:
+        gpu_ctx.uploadScene(d)
+    assert e.value.status == _abi.ERR_LIMIT
+    ng[0] = 7
+    types2[big - 1] = _abi.GEOM_SPHERE
+    ch2[2 * (big - 1)] = ch2[2 * (big - 1) + 1] = -1
+    gpu_ctx.uploadScene(d)                      # no CsgOp left: accepted
 
 
 def _load_text(tmp_path, text, name="s.sdl"):
