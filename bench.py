@@ -94,9 +94,13 @@ class FramePipe:
     the render of frame i+1 (separate streams)."""
 
     def __init__(self, torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, strip_height, dev, overlap,
-                 backend="nccl", gather_format="float"):
+                 backend="nccl", gather_format="float", exchange="gather"):
         self.torch, self.dist, self.ctx, self.cam = torch, dist, ctx, cam
         self.backend = backend
+        # "gather": one RCCL gather of every rank's strips into a rank-major buffer + a de-interleave pass on rank 0.
+        # "p2p":    a strip of full rows is contiguous in the frame, so rank 0 posts one receive per remote strip
+        #           straight into its final place (batched isend/irecv): no gather buffer, no de-interleave pass.
+        self.p2p = exchange == "p2p" and world > 1
         # "float": gather the Image!Color frame (12 B/pixel, the reference's contract).
         # "rgb32": each rank display-encodes its strips (Color.toRGB32) and 4 B/pixel cross xGMI.
         self.rgb32 = gather_format == "rgb32" and world > 1
@@ -111,16 +115,24 @@ class FramePipe:
         # what crosses the links: the float strips themselves, or their packed RGB32 encoding
         self.wire = self.local if not self.rgb32 else [torch.zeros((self.plan.rows_pad, width), dtype=torch.int32, device=dev) for _ in range(nbuf)]
         wshape, wdtype = tuple(self.wire[0].shape), self.wire[0].dtype
-        self.gathered = self.frame = None
+        self.gathered = self.frame = self.frames = None
+        sh = self.plan.strip_height
+        # (first frame row, rows, owner, first row in the owner's compact buffer) of every strip
+        self.strips = [(s * sh, min(sh, height - s * sh), s % world, (s // world) * sh) for s in range((height + sh - 1) // sh)]
         if world > 1 and rank == 0:
-            self.gathered = [torch.empty((world,) + wshape, dtype=wdtype, device=dev) for _ in range(nbuf)]
-            self.frame = torch.empty((height,) + wshape[1:], dtype=wdtype, device=dev)
+            if self.p2p:
+                self.frames = [torch.empty((height,) + wshape[1:], dtype=wdtype, device=dev) for _ in range(nbuf)]
+                self.frame = self.frames[0]
+            else:
+                self.gathered = [torch.empty((world,) + wshape, dtype=wdtype, device=dev) for _ in range(nbuf)]
+                self.frame = torch.empty((height,) + wshape[1:], dtype=wdtype, device=dev)
         self.side = torch.cuda.Stream(dev) if self.overlap else None
         self.cpu_stage = self.cpu_list = None
-        if backend == "gloo" and world > 1:   # rehearsal only: gloo gathers host tensors
+        if backend == "gloo" and world > 1:   # rehearsal only: gloo moves host tensors
             self.cpu_stage = [torch.empty(wshape, dtype=wdtype) for _ in range(nbuf)]
             if rank == 0:
                 self.cpu_list = [[torch.empty(wshape, dtype=wdtype) for _ in range(world)] for _ in range(nbuf)]
+                self.cpu_frame = [torch.empty((height,) + wshape[1:], dtype=wdtype) for _ in range(nbuf)] if self.p2p else None
         self.work = [None] * nbuf       # outstanding gather per buffer
         self.post = [None] * nbuf       # event: rank 0 finished reading gathered[b]
         self.i = 0
@@ -143,6 +155,36 @@ class FramePipe:
             return dist.gather(self.cpu_stage[b], self.cpu_list[b] if self.rank == 0 else None, dst=0, async_op=async_op)
         return dist.gather(self.wire[b], list(self.gathered[b].unbind(0)) if self.rank == 0 else None, dst=0, async_op=async_op)
 
+    def _exchange_p2p(self, b):
+        """Rank 0: own strips copied into place, one irecv per remote strip into its final rows of frames[b];
+        the others: one isend per own strip.  Returns the outstanding works."""
+        dist, torch = self.dist, self.torch
+        gloo = self.backend == "gloo"
+        if gloo:
+            self.stream.synchronize()
+            self.cpu_stage[b].copy_(self.wire[b])
+        src = self.cpu_stage[b] if gloo else self.wire[b]
+        ops = []
+        if self.rank == 0:
+            dst = self.cpu_frame[b] if gloo else self.frames[b]
+            for (y0, n, owner, lr) in self.strips:
+                if owner == 0:
+                    self.frames[b][y0:y0 + n].copy_(self.wire[b][lr:lr + n], non_blocking=True)
+                else:
+                    ops.append(dist.P2POp(dist.irecv, dst[y0:y0 + n], owner))
+        else:
+            for (y0, n, owner, lr) in self.strips:
+                if owner == self.rank:
+                    ops.append(dist.P2POp(dist.isend, src[lr:lr + n], 0))
+        self.frame = self.frames[b] if self.rank == 0 else None
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _landed_p2p(self, b):
+        if self.backend == "gloo" and self.rank == 0:      # rehearsal: the received host rows go to the device frame
+            for (y0, n, owner, lr) in self.strips:
+                if owner != 0:
+                    self.frames[b][y0:y0 + n].copy_(self.cpu_frame[b][y0:y0 + n])
+
     def _landed(self, b):
         if self.backend == "gloo" and self.rank == 0:
             for r in range(self.world):
@@ -157,6 +199,21 @@ class FramePipe:
         torch, dist = self.torch, self.dist
         if self.world == 1:
             self.render(0, events)
+            return
+        if self.p2p:
+            b = self.i % 2 if self.overlap else 0
+            self.i += 1
+            if self.work[b] is not None:              # the exchange that used local[b] / frames[b] last time is done
+                for w in self.work[b]:
+                    w.wait()
+                self._landed_p2p(b)
+            self.render(b, events)
+            self.work[b] = self._exchange_p2p(b)
+            if not self.overlap:
+                for w in self.work[b]:
+                    w.wait()
+                self._landed_p2p(b)
+                self.work[b] = None
             return
         if not self.overlap:
             self.render(0, events)
@@ -184,6 +241,14 @@ class FramePipe:
             self.work[b] = self._gather(b, True)
 
     def drain(self):
+        if self.p2p:
+            for b, ws in enumerate(self.work):
+                if ws is not None:
+                    for w in ws:
+                        w.wait()
+                    self._landed_p2p(b)
+                    self.work[b] = None
+            return
         for w in self.work:
             if w is not None:
                 w.wait()
@@ -236,11 +301,14 @@ def main():
     ap.add_argument("--no-others", action="store_true", help="N=1: skip the other BASELINE configs")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--strip-height", type=int, default=8)
+    ap.add_argument("--strip-height", type=int, default=0, help="rows per strip (multiple of 8); default 8 (gather) / 32 (p2p: one message per strip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = single-GPU rehearsal of the N>1 flow: host-staged gather, every rank on device 0")
     ap.add_argument("--gather", default="float", choices=["float", "rgb32"],
                     help="N>1: what crosses xGMI — the float Image!Color strips (default) or their RGB32 display encoding (4 B/pixel)")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "p2p"],
+                    help="N>1: one RCCL gather + de-interleave pass on rank 0 (default), or one receive per remote strip "
+                         "straight into its place in the frame (no gather buffer, no de-interleave pass)")
     ap.add_argument("--check", action="store_true", help="N>1: compare the gathered frame with a single-rank render (bit-exact)")
     args = ap.parse_args()
 
@@ -277,8 +345,9 @@ def main():
         scene.setDof(dof)
         cam = scene.beginFrame()
         ctx.uploadScene(scene.desc)
-        pipe = FramePipe(torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, args.strip_height, dev,
-                         not args.no_overlap, args.backend, args.gather)
+        strip_height = args.strip_height or (32 if args.exchange == "p2p" else 8)
+        pipe = FramePipe(torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, strip_height, dev,
+                         not args.no_overlap, args.backend, args.gather, args.exchange)
         primary, shadow = count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev)
         elapsed, kernel_ms = measure(torch, dist, pipe, steps, warmup, world, dev)
         return dict(scene=scene, cam=cam, pipe=pipe, scene_file=scene_file, width=width, height=height, taps=taps,
@@ -354,8 +423,9 @@ def main():
                 "workload": "%s %dx%d, %d tap(s)/pixel%s, dof off%s" % (
                     r["scene_file"], r["width"], r["height"], r["taps"],
                     " (AAEnabled as shipped: reference 5-tap AA)" if r["taps"] == 5 else "",
-                    "" if world == 1 else "; %d ranks x interleaved %d-row strips + RCCL gather to rank 0 (%s, %s strips)" % (
-                        world, pipe.plan.strip_height, "double-buffered" if pipe.overlap else "serial",
+                    "" if world == 1 else "; %d ranks x interleaved %d-row strips + %s to rank 0 (%s, %s strips)" % (
+                        world, pipe.plan.strip_height,
+                        "per-strip RCCL send/recv into place" if pipe.p2p else "RCCL gather", "double-buffered" if pipe.overlap else "serial",
                         "RGB32-encoded" if pipe.rgb32 else "float RGB")),
                 "name": args.workload,
                 "primary_rays_per_frame": r["primary"],
