@@ -8,11 +8,11 @@ from . import _abi
 from ._abi import (CameraFrame, HostCamera, HostSettings, RayStats, RenderOpts, SceneDesc, TraceResult,
                    TAPS_1, TAPS_4, TAPS_REF5)
 from .api import (C2rtError, Context, Renderer, Scene, loadBmpImage, parseSceneFromFile, renderPixel, saveBmp)
-from .sharding import (StripPlan, deinterleave_strips_torch, local_rows, plan_strips, render_frame_sharded)
+from .sharding import (StripPlan, deinterleave_strips_torch, exchange_strips_p2p, local_rows, plan_strips, render_frame_sharded)
 
 __all__ = [
     "C2rtError", "Context", "Renderer", "Scene", "parseSceneFromFile", "renderPixel", "loadBmpImage", "saveBmp",
     "CameraFrame", "HostCamera", "HostSettings", "RayStats", "RenderOpts", "SceneDesc", "TraceResult",
     "TAPS_1", "TAPS_4", "TAPS_REF5",
-    "StripPlan", "plan_strips", "local_rows", "render_frame_sharded", "deinterleave_strips_torch",
+    "StripPlan", "plan_strips", "local_rows", "render_frame_sharded", "deinterleave_strips_torch", "exchange_strips_p2p",
 ]

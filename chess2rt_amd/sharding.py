@@ -76,3 +76,28 @@ def render_frame_sharded(render_strips, width, height, plan, rank, group=None, d
     else:
         frame = deinterleave_strips_torch(gathered, height, plan.strip_height, world)
     return frame, local
+
+
+def exchange_strips_p2p(local, frame, height, plan, rank, group=None):
+    """The gather-free exchange: a strip of full rows is contiguous in the frame, so rank 0 copies its
+    own strips into place and posts one receive per remote strip straight into `frame[y0:y0+n]`; every
+    other rank posts one send per own strip (batched isend/irecv — RCCL send/recv over xGMI with the
+    `nccl` backend).  No rank-major gather buffer and no de-interleave pass.  `local` is this rank's
+    compact (rows_pad, ...) strip buffer, `frame` the (height, ...) result on rank 0 (None elsewhere).
+    Blocks until the exchange is complete."""
+    import torch.distributed as dist
+
+    world, sh = plan.world, plan.strip_height
+    ops = []
+    for s in range((height + sh - 1) // sh):
+        y0, n, owner, lr = s * sh, min(sh, height - s * sh), s % world, (s // world) * sh
+        if rank == 0:
+            if owner == 0:
+                frame[y0:y0 + n].copy_(local[lr:lr + n])
+            else:
+                ops.append(dist.P2POp(dist.irecv, frame[y0:y0 + n], owner, group))
+        elif owner == rank:
+            ops.append(dist.P2POp(dist.isend, local[lr:lr + n], 0, group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    return frame

@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import chess2rt_amd as c2
-from chess2rt_amd.sharding import deinterleave_strips_torch, local_rows, plan_strips, render_frame_sharded
+from chess2rt_amd.sharding import deinterleave_strips_torch, exchange_strips_p2p, local_rows, plan_strips, render_frame_sharded
 
 
 def _free_port():
@@ -44,8 +44,11 @@ def _worker(rank, world, port, name, out_path):
         local[: mine.shape[0]] = torch.from_numpy(mine)
         return local
 
-    frame, _ = render_frame_sharded(producer, W, H, plan, rank)
+    frame, local = render_frame_sharded(producer, W, H, plan, rank)
+    # the gather-free exchange (one receive per remote strip straight into the frame) assembles the same frame
+    direct = exchange_strips_p2p(local, torch.full((H, W, 3), -1.0) if rank == 0 else None, H, plan, rank)
     if rank == 0:
+        assert torch.equal(direct, frame)
         np.save(out_path, frame.numpy())
     else:
         assert frame is None
