@@ -40,8 +40,8 @@ __device__ __noinline__ double c2_sin(double a) { return sin(a); }
 __device__ __noinline__ double c2_cos(double a) { return cos(a); }
 /* Register budget, measured on MI355X (profiles/): with no hint hipcc takes all
  * 512 registers and runs one wave per SIMD (1.8x slower).  The CSG-free kernel
- * fits 4 waves/SIMD (128 VGPRs) without spills; the CSG kernels are fastest at
- * 3 waves/SIMD (168 VGPRs) — at 4 they spill, at 2 latency shows. */
+ * fits 4 waves/SIMD (128 VGPRs) without spills; the CSG kernels were fastest at
+ * 3 waves/SIMD (168 VGPRs) while their LDS slabs capped a CU at 13 waves — see below. */
 #ifndef C2RT_OCC
 #if defined(C2RT_UNIT) && C2RT_UNIT == 0
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -53,7 +53,14 @@ __device__ __noinline__ double c2_cos(double a) { return cos(a); }
  * cap residency below one wave per SIMD anyway */
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
-#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+/* depth-1 CSG kernel: with 10 KiB slabs 16 waves fit a CU's LDS, and 4 waves/SIMD with 39 spilled VGPRs
+ * (80 B of scratch per lane) are 2 % faster on multi-tap frames (lecture5 4K x5: 1.525 -> 1.490 ms) and 3 %
+ * slower on the 1-tap 4K frame — but the spills put 760 MB of scratch writes per frame on HBM (WRITE_SIZE
+ * 99.5 -> 861 MB): not worth it; 3 waves/SIMD (149 VGPRs, no scratch) stays until the kernel fits 128. */
+#ifndef C2RT_OCC_U1
+#define C2RT_OCC_U1 3
+#endif
+#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(C2RT_OCC_U1, C2RT_OCC_U1)))
 #endif
 #endif
 #ifndef C2RT_OCC_DOF
