@@ -38,6 +38,9 @@ __device__ __noinline__ double c2_atan2(double a, double b) { return atan2(a, b)
 __device__ __noinline__ double c2_asin(double a) { return asin(a); }
 __device__ __noinline__ double c2_sin(double a) { return sin(a); }
 __device__ __noinline__ double c2_cos(double a) { return cos(a); }
+/* sin and cos of the same angle share their argument reduction (same results as the two calls) */
+struct SinCos { double s, c; };
+__device__ __noinline__ SinCos c2_sincos(double a) { SinCos r; sincos(a, &r.s, &r.c); return r; }
 /* Register budget, measured on MI355X (profiles/): with no hint hipcc takes all
  * 512 registers and runs one wave per SIMD (1.8x slower).  The CSG-free kernel
  * fits 4 waves/SIMD (128 VGPRs) without spills; the CSG kernels were fastest at
@@ -969,7 +972,8 @@ DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &
         constexpr double PI = 3.14159265358979323846;
         const double angle = rng_next(rng) * 2 * PI;
         const double rad = sqrt(rng_next(rng));
-        double dx = c2_sin(angle) * rad, dy = c2_cos(angle) * rad;
+        const SinCos sc = c2_sincos(angle);
+        double dx = sc.s * rad, dy = sc.c * rad;
         dx *= cam.disc_multiplier;
         dy *= cam.disc_multiplier;
         orig = pos + rightDir * dx + ld3(cam.up_dir) * dy;
