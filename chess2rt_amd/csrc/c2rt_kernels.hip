@@ -38,9 +38,6 @@ __device__ __noinline__ double c2_atan2(double a, double b) { return atan2(a, b)
 __device__ __noinline__ double c2_asin(double a) { return asin(a); }
 __device__ __noinline__ double c2_sin(double a) { return sin(a); }
 __device__ __noinline__ double c2_cos(double a) { return cos(a); }
-/* sin and cos of the same angle share their argument reduction (same results as the two calls) */
-struct SinCos { double s, c; };
-__device__ __noinline__ SinCos c2_sincos(double a) { SinCos r; sincos(a, &r.s, &r.c); return r; }
 /* Register budget, measured on MI355X (profiles/): with no hint hipcc takes all
  * 512 registers and runs one wave per SIMD (1.8x slower).  The CSG-free kernel
  * fits 4 waves/SIMD (128 VGPRs) without spills; the CSG kernels were fastest at
@@ -938,17 +935,76 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const 
 /* camera — rt/camera.d:123-173                                          */
 /* ------------------------------------------------------------------ */
 
-DEV double rng_uniform(uint64_t seed, uint64_t pixel, uint32_t tap, uint32_t sample, uint32_t dim)
+/* Counter-based RNG for the lens samples (build-defined: the reference draws from libc rand(),
+ * util/random.d:19-28, which is not reproducible — SURVEY.md F5).  32-bit multiply-xorshift
+ * finaliser ("lowbias32"); the key folds (seed, pixel, tap) once per sample loop, a draw is one
+ * hash of key + golden-ratio * counter.  The CPU checker restates it statement for statement. */
+DEV uint32_t hash32(uint32_t x)
 {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (1 + (((pixel * 8 + tap) * 4096 + sample) * 8 + dim));
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (double)(z >> 11) * 0x1p-53;
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+DEV uint32_t rng_key(uint64_t seed, uint64_t pixel, uint32_t tap)
+{
+    uint32_t k = hash32((uint32_t)(seed >> 32) ^ 0x243f6a88u);
+    k = hash32(k ^ (uint32_t)seed);
+    k = hash32(k + (uint32_t)(pixel >> 32));
+    k = hash32(k ^ (uint32_t)pixel);
+    return hash32(k + tap);
+}
+/* uniform in [0, 1) with 32 random bits (rand()/RAND_MAX has 31) */
+DEV double rng_uniform(uint32_t key, uint32_t sample, uint32_t dim)
+{
+    return (double)hash32(key + 0x9e3779b9u * (sample * 16u + dim + 1u)) * 0x1p-32;
 }
 
-struct Rng { uint64_t seed, pixel; uint32_t tap, sample, dim; };
-DEV double rng_next(Rng &r) { return rng_uniform(r.seed, r.pixel, r.tap, r.sample, r.dim++); }
+struct Rng { uint32_t key, sample, dim; };
+DEV double rng_next(Rng &r) { return rng_uniform(r.key, r.sample, r.dim++); }
+
+/* (sin, cos)(2 pi u) for u in [0, 1) without libm, so that a CPU checker and the kernel produce the
+ * same bits (device sincos and glibc sin/cos differ by an ulp, which flips z-fights between
+ * coincident planes): exact reduction of 4u to a quadrant q and a fraction g in [0, 0.5] (mirrored
+ * about the octant boundary), then the Taylor polynomials in theta = g * (pi/2) <= pi/4 — sin to
+ * theta^17, cos to theta^16, truncation error < 1e-17 — evaluated by Horner in fp64 with contraction
+ * off (integer and IEEE +, * only: any IEEE-754 host reproduces it). */
+DEV void lens_sincos2pi(double u, double &sn, double &cs)
+{
+    const double t = u * 4.0;          /* exact */
+    const int q = (int)t;              /* 0..3 */
+    const double f = t - (double)q;    /* exact, [0, 1) */
+    const bool mirror = f > 0.5;
+    const double g = mirror ? 1.0 - f : f; /* exact */
+    const double th = g * 0x1.921fb54442d18p+0; /* pi/2 */
+    const double z = th * th;
+    double ps = 0x1.952c77030ad4ap-49;             /* +1/17! */
+    ps = -0x1.ae7f3e733b81fp-41 + z * ps;          /* -1/15! */
+    ps = 0x1.6124613a86d09p-33 + z * ps;           /* +1/13! */
+    ps = -0x1.ae64567f544e4p-26 + z * ps;          /* -1/11! */
+    ps = 0x1.71de3a556c734p-19 + z * ps;           /* +1/9! */
+    ps = -0x1.a01a01a01a01ap-13 + z * ps;          /* -1/7! */
+    ps = 0x1.1111111111111p-7 + z * ps;            /* +1/5! */
+    ps = -0x1.5555555555555p-3 + z * ps;           /* -1/3! */
+    const double s = th + th * (z * ps);
+    double pc = 0x1.ae7f3e733b81fp-45;             /* +1/16! */
+    pc = -0x1.93974a8c07c9dp-37 + z * pc;          /* -1/14! */
+    pc = 0x1.1eed8eff8d898p-29 + z * pc;           /* +1/12! */
+    pc = -0x1.27e4fb7789f5cp-22 + z * pc;          /* -1/10! */
+    pc = 0x1.a01a01a01a01ap-16 + z * pc;           /* +1/8! */
+    pc = -0x1.6c16c16c16c17p-10 + z * pc;          /* -1/6! */
+    pc = 0x1.5555555555555p-5 + z * pc;            /* +1/4! */
+    pc = -0.5 + z * pc;                            /* -1/2! */
+    const double c = 1.0 + z * pc;
+    const double a = mirror ? c : s, b = mirror ? s : c; /* sin, cos of the in-quadrant angle */
+    /* quadrant rotation: q=0 (a, b), 1 (b, -a), 2 (-a, -b), 3 (-b, a) */
+    sn = (q & 1) ? b : a;
+    cs = (q & 1) ? a : b;
+    if (q == 2 || q == 3) sn = -sn;
+    if (q == 1 || q == 2) cs = -cs;
+}
 
 template <bool DOF>
 DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &rng, D3 &orig, D3 &dir)
@@ -969,11 +1025,12 @@ DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &
         const double cosTheta = dot(dir, ld3(cam.front_dir));
         const double M = cam.focal_plane_dist / cosTheta;
         const D3 T = orig + dir * M;
-        constexpr double PI = 3.14159265358979323846;
-        const double angle = rng_next(rng) * 2 * PI;
+        /* unitDiscSample — rt/camera.d:258-269: (sin, cos)(U1 * 2 pi) * sqrt(U2) */
+        const double u1 = rng_next(rng);
         const double rad = sqrt(rng_next(rng));
-        const SinCos sc = c2_sincos(angle);
-        double dx = sc.s * rad, dy = sc.c * rad;
+        double sn, cs;
+        lens_sincos2pi(u1, sn, cs);
+        double dx = sn * rad, dy = cs * rad;
         dx *= cam.disc_multiplier;
         dy *= cam.disc_multiplier;
         orig = pos + rightDir * dx + ld3(cam.up_dir) * dy;
@@ -1050,7 +1107,7 @@ template <int LEVELS, bool DOF, bool MLC, bool PO>
 DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, int dx, int dy, uint64_t pixel, uint32_t tap,
                      Counters &cnt, c2rt_trace_result *probe)
 {
-    Rng rng = {P.seed, pixel, tap, 0, 0};
+    Rng rng = {DOF ? rng_key(P.seed, pixel, tap) : 0u, 0, 0};
     D3 o, d;
     if constexpr (!DOF) {
         screen_ray<false>(P, x, y, 0, rng, o, d);

@@ -758,18 +758,74 @@ void orc_camera_begin_frame(const double pos_[3], double yaw, double pitch, doub
     out->frame_height = (double)frame_height;
 }
 
-/* splitmix64-based counter RNG (build-defined; the reference uses rand()) */
+/* Counter-based RNG for the lens samples (build-defined; the reference draws from libc rand(),
+ * util/random.d:19-28, which is not reproducible): 32-bit multiply-xorshift finaliser; the key
+ * folds (seed, pixel, tap), a draw is one hash of key + golden-ratio * counter.  Same statement
+ * sequence as rng_key / rng_uniform in chess2rt_amd/csrc/c2rt_kernels.hip. */
+static inline uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+static uint32_t rng_key(uint64_t seed, uint64_t pixel, uint32_t tap)
+{
+    uint32_t k = hash32((uint32_t)(seed >> 32) ^ 0x243f6a88u);
+    k = hash32(k ^ (uint32_t)seed);
+    k = hash32(k + (uint32_t)(pixel >> 32));
+    k = hash32(k ^ (uint32_t)pixel);
+    return hash32(k + tap);
+}
 double orc_rng_uniform(uint64_t seed, uint64_t pixel, uint32_t tap, uint32_t sample, uint32_t dim)
 {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (1 + (((pixel * 8 + tap) * 4096 + sample) * 8 + dim));
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (double)(z >> 11) * 0x1p-53;
+    uint32_t key = rng_key(seed, pixel, tap);
+    return (double)hash32(key + 0x9e3779b9u * (sample * 16u + dim + 1u)) * 0x1p-32;
 }
 
 typedef struct { uint64_t seed, pixel; uint32_t tap, sample, dim; } Rng;
 static double rng_next(Rng *r) { return orc_rng_uniform(r->seed, r->pixel, r->tap, r->sample, r->dim++); }
+
+/* (sin, cos)(2 pi u), u in [0, 1), without libm: the lens sample must have the same bits here and
+ * on the device (glibc sin/cos and the device's differ by an ulp, which flips z-fights between
+ * coincident planes).  Exact reduction to a quadrant and a mirrored fraction, then Taylor
+ * polynomials on [0, pi/4] by Horner (truncation error < 1e-17); -ffp-contract=off on both sides.
+ * Same statement sequence as lens_sincos2pi in c2rt_kernels.hip. */
+void orc_lens_sincos2pi(double u, double *sn, double *cs)
+{
+    const double t = u * 4.0;
+    const int q = (int)t;
+    const double f = t - (double)q;
+    const int mirror = f > 0.5;
+    const double g = mirror ? 1.0 - f : f;
+    const double th = g * 0x1.921fb54442d18p+0; /* pi/2 */
+    const double z = th * th;
+    double ps = 0x1.952c77030ad4ap-49;             /* +1/17! */
+    ps = -0x1.ae7f3e733b81fp-41 + z * ps;          /* -1/15! */
+    ps = 0x1.6124613a86d09p-33 + z * ps;           /* +1/13! */
+    ps = -0x1.ae64567f544e4p-26 + z * ps;          /* -1/11! */
+    ps = 0x1.71de3a556c734p-19 + z * ps;           /* +1/9! */
+    ps = -0x1.a01a01a01a01ap-13 + z * ps;          /* -1/7! */
+    ps = 0x1.1111111111111p-7 + z * ps;            /* +1/5! */
+    ps = -0x1.5555555555555p-3 + z * ps;           /* -1/3! */
+    const double s = th + th * (z * ps);
+    double pc = 0x1.ae7f3e733b81fp-45;             /* +1/16! */
+    pc = -0x1.93974a8c07c9dp-37 + z * pc;          /* -1/14! */
+    pc = 0x1.1eed8eff8d898p-29 + z * pc;           /* +1/12! */
+    pc = -0x1.27e4fb7789f5cp-22 + z * pc;          /* -1/10! */
+    pc = 0x1.a01a01a01a01ap-16 + z * pc;           /* +1/8! */
+    pc = -0x1.6c16c16c16c17p-10 + z * pc;          /* -1/6! */
+    pc = 0x1.5555555555555p-5 + z * pc;            /* +1/4! */
+    pc = -0.5 + z * pc;                            /* -1/2! */
+    const double c = 1.0 + z * pc;
+    const double a = mirror ? c : s, b = mirror ? s : c;
+    *sn = (q & 1) ? b : a;
+    *cs = (q & 1) ? a : b;
+    if (q == 2 || q == 3) *sn = -*sn;
+    if (q == 1 || q == 2) *cs = -*cs;
+}
 
 /* Camera.getScreenRay — rt/camera.d:123-173; offset: 0 none, -1 left, +1 right */
 static Ray screen_ray(const c2rt_camera_frame *cam, double x, double y, int offset, Rng *rng)
@@ -792,10 +848,12 @@ static Ray screen_ray(const c2rt_camera_frame *cam, double x, double y, int offs
     double M = cam->focal_plane_dist / cosTheta;
     V3 T = vadd(result.orig, vmul(result.dir, M));
     /* unitDiscSample — rt/camera.d:258-269 */
-    double angle = rng_next(rng) * 2 * ORC_PI;
+    double u1 = rng_next(rng);
     double rad = sqrt(rng_next(rng));
-    double dx = sin(angle) * rad;
-    double dy = cos(angle) * rad;
+    double sn, cs;
+    orc_lens_sincos2pi(u1, &sn, &cs); /* sin(angle), cos(angle), angle = U * 2 pi */
+    double dx = sn * rad;
+    double dy = cs * rad;
     dx *= cam->disc_multiplier;
     dy *= cam->disc_multiplier;
     result.orig = vadd(vadd(pos, vmul(rightDir, dx)), vmul(upDir, dy));

@@ -104,6 +104,9 @@ uint32_t orc_color_to_rgb32(const float rgb[3]);
  * reference uses libc rand()): uniform in [0,1). */
 double orc_rng_uniform(uint64_t seed, uint64_t pixel, uint32_t tap,
                        uint32_t sample, uint32_t dim);
+/* (sin, cos)(2 pi u) for u in [0,1) of the lens sample (rt/camera.d:258-269),
+ * libm-free so that the device produces the same bits. */
+void orc_lens_sincos2pi(double u, double *sn, double *cs);
 
 #ifdef __cplusplus
 }
