@@ -21,7 +21,7 @@ UNITS      := 0 1 2 3 4 5
 KOBJS      := $(foreach u,$(UNITS),$(BUILD)/c2rt_kernels_u$(u).o)
 HOBJS      := $(BUILD)/c2rt_api.o $(BUILD)/dsc.o $(BUILD)/scene.o $(BUILD)/host_api.o
 
-all: $(LIBNAME) oracle/libc2rt_oracle.so
+all: $(LIBNAME) oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so
 
 $(BUILD):
 	mkdir -p $(BUILD)
@@ -42,7 +42,11 @@ $(LIBNAME): $(KOBJS) $(HOBJS)
 oracle/libc2rt_oracle.so: oracle/c2rt_oracle.c oracle/c2rt_oracle.h include/c2rt.h
 	$(CC) -O2 -std=gnu11 -fPIC -shared $(FPFLAGS) -Wall -o $@ oracle/c2rt_oracle.c -lm -lpthread
 
+# the same restatement with its arithmetic statements tallied (algorithmic fp op count for bench.py's roofline.flops)
+oracle/libc2rt_oracle_count.so: oracle/c2rt_oracle.c oracle/c2rt_oracle.h include/c2rt.h
+	$(CC) -O2 -std=gnu11 -fPIC -shared $(FPFLAGS) -Wall -DORC_COUNT_OPS -o $@ oracle/c2rt_oracle.c -lm -lpthread
+
 clean:
-	rm -rf build build_* chess2rt_amd/libc2rt*.so oracle/libc2rt_oracle.so
+	rm -rf build build_* chess2rt_amd/libc2rt*.so oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so
 
 .PHONY: all clean

@@ -48,6 +48,24 @@ WORKLOADS = {
 
 VALU_PEAK_TSLOTS = 256 * 4 * 16 * 2.4e9 / 1e12  # CUs x SIMDs x lanes/clk x clock (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# fp64 vector peak counted as SEPARATE operations: the path is built with contraction off (the reference's
+# x86-64 code has no FMA), so an add or a mul fills a lane slot each — 39.3 T op/s, half the 78.6 TFLOP/s FMA figure
+FP64_PEAK_TOPS = VALU_PEAK_TSLOTS
+
+
+def kernel_source_hash():
+    """Identifies the kernels a committed PMC profile was taken on: sha256 over the device sources and the
+    build flags.  profiles/traffic_<workload>.json carries the hash of the tree it was measured on; bench.py
+    reports its instruction / traffic counts only when it equals the hash of the tree that built the loaded
+    library (a stale profile is reported as such, never silently combined with a live time)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in ("chess2rt_amd/csrc/c2rt_kernels.hip", "chess2rt_amd/csrc/c2rt_device.h", "include/c2rt.h", "Makefile"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    h.update(os.environ.get("C2RT_LIB_VARIANT", "").encode())
+    return h.hexdigest()[:16]
 
 
 def weak_frame(width, height, n):
@@ -58,12 +76,21 @@ def weak_frame(width, height, n):
     return int(round(width * s / 8)) * 8, int(round(height * s / 8)) * 8
 
 
-def cpu_baseline(scene, cam, opts, rays_per_frame, budget_s=12.0):
-    """The CPU oracle (restatement of the reference algorithm, NOT the D
-    binary — no D toolchain exists here) timed on this box's host cores."""
+def cpu_baseline(c2, scene_file, width, height, taps, dof, rays_per_frame, budget_s=12.0):
+    """The CPU oracle (restatement of the reference algorithm, NOT the D binary — no D toolchain exists
+    here) timed on this box's host cores: full frames of the workload on all cores, a bounded one-thread
+    sample (the same scene and taps at 1/4 x 1/4 of the frame: 1/16 of the rays) for the per-core figure,
+    and one pass of the counting build for the algorithmic floating-point operation count."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
+    def load(w, h):
+        sc = c2.parseSceneFromFile(os.path.join(SCENES, scene_file))
+        sc.setFrameSize(w, h)
+        sc.setDof(dof)
+        return sc, sc.beginFrame(), sc.renderOpts(taps=taps)
+
+    scene, cam, opts = load(width, height)
     cores = len(os.sched_getaffinity(0))
     times = []
     t_all = time.time()
@@ -76,15 +103,70 @@ def cpu_baseline(scene, cam, opts, rays_per_frame, budget_s=12.0):
         if warm > budget_s and len(times) >= 1:
             break
     med = statistics.median(times)
+    # one thread, bounded: 1/16 of the pixels of the same view
+    sw, sh = max(8, width // 4), max(8, height // 4)
+    s1, c1, o1 = load(sw, sh)
+    st1 = {}
+    t = time.time()
+    oracle_lib.render_frame(s1.desc, c1, o1, 1, st1)
+    t1 = time.time() - t
+    one = (st1["primary"] + st1["shadow"]) / t1 / 1e6
+    # algorithmic operation count of one full frame (counting build, all cores, untimed)
+    ops, _ = oracle_lib.op_counts(scene.desc, cam, opts, cores)
+    value = rays_per_frame / med / 1e6
     return {
-        "value": rays_per_frame / med / 1e6,
+        "value": value,
         "unit": "Mray/s",
         "ms_per_frame": med * 1e3,
         "cores": cores,
         "kind": "port",
         "sample": "%d full frames of the same workload (%dx%d, %d tap(s)) after 1 warm-up, median; pthread pool over 48x48 buckets"
                   % (len(times), opts.width, opts.height, opts.taps),
-    }
+        "one_thread": {"value": one, "unit": "Mray/s", "seconds": t1,
+                       "sample": "1 frame of the same scene and taps at %dx%d (1/16 of the rays), 1 thread" % (sw, sh)},
+        "scaling_vs_one_thread": value / one,
+        "cpu_model": cpu_model(),
+    }, ops
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def boundary_timings(np, ctx, cam, opts, n=10):
+    """ms/frame at the reference's actual boundary (renderRT writes the caller's HOST Image!Color,
+    rt/renderer.d:83-192): c2rt_render_frame into a buffer pinned with c2rt_pin_host_buffer (kernel + D2H,
+    chunked and overlapped) and c2rt_render_frame_rgb32 (display words, a third of the bytes).  PCIe-inclusive:
+    reported beside `value`, never as `value`."""
+    out = {}
+    h, w = opts.height, opts.width
+    buf = np.empty((h, w, 3), np.float32)
+    ctx.pinHostBuffer(buf)
+    try:
+        ctx.renderFrameInto(cam, opts, buf)
+        t = time.perf_counter()
+        for _ in range(n):
+            ctx.renderFrameInto(cam, opts, buf)
+        out["host_float_pinned_ms"] = (time.perf_counter() - t) / n * 1e3
+    finally:
+        ctx.unpinHostBuffer(buf)
+    b32 = np.empty((h, w), np.uint32)
+    ctx.pinHostBuffer(b32)
+    try:
+        ctx.renderFrameRGB32Into(cam, opts, b32)
+        t = time.perf_counter()
+        for _ in range(n):
+            ctx.renderFrameRGB32Into(cam, opts, b32)
+        out["host_rgb32_pinned_ms"] = (time.perf_counter() - t) / n * 1e3
+    finally:
+        ctx.unpinHostBuffer(b32)
+    return out
 
 
 class FramePipe:
@@ -281,6 +363,42 @@ def measure(torch, dist, pipe, steps, warmup, world, dev):
     return float(el.item()), kernel_ms
 
 
+def phase_probe(torch, dist, pipe, world, dev, n=3):
+    """N>1: host-clocked phases of a SERIAL frame (barrier + device sync between phases), mean of n:
+    render (every rank's strips), exchange (gather or per-strip send/recv, all ranks), de-interleave
+    (rank 0).  Diagnostic, outside the timed region; the timed loop overlaps these."""
+    def sync():
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    acc = [0.0, 0.0, 0.0]
+    for _ in range(n):
+        sync()
+        t0 = time.perf_counter()
+        pipe.render(0)
+        sync()
+        t1 = time.perf_counter()
+        if pipe.p2p:
+            for w in pipe._exchange_p2p(0):
+                w.wait()
+            pipe._landed_p2p(0)
+        else:
+            pipe._gather(0, False)
+        sync()
+        t2 = time.perf_counter()
+        if not pipe.p2p and pipe.rank == 0:
+            pipe._landed(0)
+            pipe._deinterleave(0, pipe.stream)
+        sync()
+        t3 = time.perf_counter()
+        acc[0] += t1 - t0
+        acc[1] += t2 - t1
+        acc[2] += t3 - t2
+    return {"render_ms": acc[0] / n * 1e3, "exchange_ms": acc[1] / n * 1e3, "deinterleave_ms": acc[2] / n * 1e3,
+            "note": "serial frame with a barrier between phases (host clock incl. ~2 barriers of latency per phase), mean of %d" % n}
+
+
 def count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev):
     copts = scene.renderOpts(taps=taps, strip_height=pipe.plan.strip_height, strip_rank=rank, strip_world=world, count_rays=1)
     ctx.renderFrameDevice(cam, copts, pipe.local[0].data_ptr(), pipe.stream.cuda_stream)
@@ -301,11 +419,15 @@ def main():
     ap.add_argument("--no-others", action="store_true", help="N=1: skip the other BASELINE configs")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true", help="N=1: skip the host-output (PCIe-inclusive) timings")
     ap.add_argument("--strip-height", type=int, default=0, help="rows per strip (multiple of 8); default 8 (gather) / 32 (p2p: one message per strip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = single-GPU rehearsal of the N>1 flow: host-staged gather, every rank on device 0")
-    ap.add_argument("--gather", default="float", choices=["float", "rgb32"],
-                    help="N>1: what crosses xGMI — the float Image!Color strips (default) or their RGB32 display encoding (4 B/pixel)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "float", "rgb32"],
+                    help="N>1: what crosses xGMI — the float Image!Color strips (12 B/pixel) or their RGB32 display encoding "
+                         "(Color.toRGB32 on each rank, 4 B/pixel).  auto (default): a calibration pass times one render and one "
+                         "serial float exchange; float is kept when its exchange fits inside 0.9 x the render time (so double "
+                         "buffering hides it), otherwise the strips cross the links display-encoded")
     ap.add_argument("--exchange", default="gather", choices=["gather", "p2p"],
                     help="N>1: one RCCL gather + de-interleave pass on rank 0 (default), or one receive per remote strip "
                          "straight into its place in the frame (no gather buffer, no de-interleave pass)")
@@ -335,6 +457,21 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    ranks_seen = 1
+    devices = None
+    if world > 1:
+        # what the process group actually spans: one rank per GPU, N of them, or fail
+        ones = torch.ones(1, dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if dist.get_world_size() != args.gpus or ranks_seen != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the process group has %d ranks (all_reduce counted %d)"
+                             % (args.gpus, dist.get_world_size(), ranks_seen))
+        devices = [None] * world
+        dist.all_gather_object(devices, "%s:%d" % (torch.cuda.get_device_name(local_rank), local_rank))
+        if args.backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit("bench.py: %d ranks but only %d GPUs visible" % (world, torch.cuda.device_count()))
+
     ctx = c2.Context(local_rank)
 
     def run(workload, steps, warmup):
@@ -346,12 +483,31 @@ def main():
         cam = scene.beginFrame()
         ctx.uploadScene(scene.desc)
         strip_height = args.strip_height or (32 if args.exchange == "p2p" else 8)
+        gather_format, calib = args.gather, None
+        if world == 1:
+            gather_format = "float"
+        elif gather_format == "auto":
+            # calibrate: can a float exchange hide behind a render?  (rank 0 decides for everybody)
+            probe_pipe = FramePipe(torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, strip_height, dev,
+                                   False, args.backend, "float", args.exchange)
+            phase_probe(torch, dist, probe_pipe, world, dev, n=1)  # warm-up (RCCL channel setup)
+            calib = phase_probe(torch, dist, probe_pipe, world, dev, n=3)
+            flag = torch.tensor([1 if calib["exchange_ms"] <= 0.9 * calib["render_ms"] else 0], dtype=torch.int32,
+                                device=dev if args.backend == "nccl" else "cpu")
+            dist.broadcast(flag, 0)
+            gather_format = "float" if int(flag.item()) else "rgb32"
+            calib["chosen"] = gather_format
+            calib["rule"] = "float if exchange_ms <= 0.9 * render_ms (serial probe), else rgb32"
+            del probe_pipe
+            torch.cuda.empty_cache()
         pipe = FramePipe(torch, dist, c2, ctx, scene, cam, taps, width, height, world, rank, strip_height, dev,
-                         not args.no_overlap, args.backend, args.gather, args.exchange)
+                         not args.no_overlap, args.backend, gather_format, args.exchange)
         primary, shadow = count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev)
         elapsed, kernel_ms = measure(torch, dist, pipe, steps, warmup, world, dev)
-        return dict(scene=scene, cam=cam, pipe=pipe, scene_file=scene_file, width=width, height=height, taps=taps,
-                    primary=primary, shadow=shadow, elapsed=elapsed, kernel_ms=kernel_ms, steps=steps)
+        phases = phase_probe(torch, dist, pipe, world, dev) if world > 1 else None
+        return dict(scene=scene, cam=cam, pipe=pipe, scene_file=scene_file, width=width, height=height, taps=taps, dof=dof,
+                    primary=primary, shadow=shadow, elapsed=elapsed, kernel_ms=kernel_ms, steps=steps, phases=phases,
+                    calib=calib)
 
     r = run(args.workload, args.steps, args.warmup)
 
@@ -388,6 +544,12 @@ def main():
         # leave the context on the headline scene for the CPU baseline below
         ctx.uploadScene(r["scene"].desc)
 
+    boundary = None
+    if world == 1 and rank == 0 and not args.no_boundary:
+        import numpy as np
+
+        boundary = boundary_timings(np, ctx, r["cam"], r["scene"].renderOpts(taps=r["taps"]))
+
     if rank == 0:
         scene, pipe = r["scene"], r["pipe"]
         rays_per_frame = r["primary"] + r["shadow"]
@@ -397,17 +559,26 @@ def main():
         tex_bytes = int(scene.desc.contents.n_texels) * 12
         alg_bytes = pipe.my_rows * r["width"] * 12 + tex_bytes
         achieved = alg_bytes / (r["kernel_ms"] * 1e-3) / 1e9
+        # PMC counts come from a committed profile and are only valid for the kernels they were taken on
         traffic = valu_insts = None
+        profile_state = "absent"
+        khash = kernel_source_hash()
         prof = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if world == 1 and os.path.exists(prof):
             try:
                 prof_data = json.load(open(prof))
-                traffic = prof_data.get("hbm_bytes_per_launch")
-                valu_insts = prof_data.get("valu_insts_per_launch")
-            except Exception:
-                traffic = None
+                if prof_data.get("kernel_source_hash") == khash:
+                    traffic = prof_data.get("hbm_bytes_per_launch")
+                    valu_insts = prof_data.get("valu_insts_per_launch")
+                    profile_state = "matches the built kernels (%s)" % khash
+                else:
+                    profile_state = "stale: taken on kernels %s, this tree is %s — counts withheld" % (
+                        prof_data.get("kernel_source_hash", "unknown (round-1 profile)"), khash)
+            except Exception as e:  # noqa: BLE001
+                profile_state = "unreadable: %s" % e
         out = {
-            "metric": "Mray/s (primary + shadow rays actually cast per second; ms/frame in ms_per_step)",
+            "metric": "Mray/s (reference-equivalent rays per second: one primary ray per sample + one shadow ray per "
+                      "(hit, lit light), counted as the reference casts them; ms/frame in ms_per_step)",
             "value": value,
             "unit": "Mray/s",
             "n_gpus": world,
@@ -420,9 +591,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic: the reference's own scene file and textures (tests/golden/scenes), fixed camera",
             "config": {
-                "workload": "%s %dx%d, %d tap(s)/pixel%s, dof off%s" % (
+                "workload": "%s %dx%d, %d tap(s)/pixel%s, dof %s%s" % (
                     r["scene_file"], r["width"], r["height"], r["taps"],
                     " (AAEnabled as shipped: reference 5-tap AA)" if r["taps"] == 5 else "",
+                    "on" if r["dof"] else "off",
                     "" if world == 1 else "; %d ranks x interleaved %d-row strips + %s to rank 0 (%s, %s strips)" % (
                         world, pipe.plan.strip_height,
                         "per-strip RCCL send/recv into place" if pipe.p2p else "RCCL gather", "double-buffered" if pipe.overlap else "serial",
@@ -444,18 +616,38 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": r["kernel_ms"],
+                "pmc_profile": profile_state,
                 "note": "by the numbers this path is fp64-VALU bound, not HBM bound (DESIGN.md 4.1): 12 B/pixel is all it must move",
             },
         }
+        if world > 1:
+            out["config"]["ranks_seen_by_collective"] = ranks_seen
+            out["config"]["devices"] = devices
+            out["config"]["phases_ms"] = r["phases"]
+            out["config"]["wire_format"] = "rgb32" if pipe.rgb32 else "float"
+            if r["calib"]:
+                out["config"]["wire_format_calibration"] = r["calib"]
+        if boundary:
+            # kernel-only / host float frame / host display frame, ms per frame (the reference's renderRT boundary is the host one)
+            out["config"]["boundary_ms"] = dict(kernel_only_ms=r["kernel_ms"], **boundary)
         if valu_insts:
             # what actually bounds this kernel: VALU issue slots (fp64 runs at the full 16 lanes/clk/SIMD rate).
-            # Instruction count from the committed PMC pass, duration measured live.
+            # Instruction count from the committed PMC pass of THESE kernels (hash checked), duration measured live.
             slots = valu_insts * 64 / (r["kernel_ms"] * 1e-3) / 1e12
             out["roofline"]["valu"] = {"achieved": slots, "peak": VALU_PEAK_TSLOTS, "unit": "T lane-slots/s", "frac": slots / VALU_PEAK_TSLOTS,
                                        "insts_per_launch": valu_insts, "source": "SQ_INSTS_VALU, profiles/traffic_%s.json" % args.workload}
         if world == 1 and not args.no_cpu_baseline:
-            full = scene.renderOpts(taps=r["taps"])
-            out["cpu_baseline"] = cpu_baseline(scene, r["cam"], full, rays_per_frame)
+            base, ops = cpu_baseline(c2, r["scene_file"], r["width"], r["height"], r["taps"], r["dof"], rays_per_frame)
+            out["cpu_baseline"] = base
+            # algorithmic fp64 operations of the frame as the reference's source executes it (instrumented
+            # oracle), over the live kernel time, against the non-fused fp64 vector peak
+            tops = ops["fp64"] / (r["kernel_ms"] * 1e-3) / 1e12
+            out["roofline"]["flops"] = {
+                "achieved": tops, "peak": FP64_PEAK_TOPS, "unit": "T fp64 op/s (non-fused)", "frac": tops / FP64_PEAK_TOPS,
+                "algorithmic_fp64_ops_per_launch": ops["fp64"], "ops": ops,
+                "note": "reference op count / kernel time: the kernel skips part of that work exactly (culling masks, "
+                        "bounding rejects, sign tests, lazy u,v), so this can exceed the fraction of issue slots it fills",
+            }
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -30,6 +30,48 @@
 #include <unistd.h>
 
 /* ===================================================================== */
+/* algorithmic operation count ("exact count from an     */
+/* instrumented CPU oracle")                                              */
+/* ===================================================================== */
+
+/* Built with -DORC_COUNT_OPS (oracle/libc2rt_oracle_count.so) every arithmetic statement of the
+ * render path tallies the floating-point operations the reference executes for it, as written in
+ * the D source: fp64 add/sub, mul, div, sqrt, libm calls (atan2 asin sin cos pow floor), and the
+ * fp32 colour add, mul, div.  Compares, negations, conversions and integer work are not counted.
+ * The timed library is built without it (the tallies are thread-local increments). */
+#ifdef ORC_COUNT_OPS
+static __thread orc_op_counts t_ops;
+static orc_op_counts g_ops;
+static pthread_mutex_t g_ops_lock = PTHREAD_MUTEX_INITIALIZER;
+#define OPS(field, n) (t_ops.field += (uint64_t)(n))
+static void ops_flush(void)
+{
+    pthread_mutex_lock(&g_ops_lock);
+    g_ops.dadd += t_ops.dadd; g_ops.dmul += t_ops.dmul; g_ops.ddiv += t_ops.ddiv; g_ops.dsqrt += t_ops.dsqrt;
+    g_ops.dlibm += t_ops.dlibm; g_ops.fadd += t_ops.fadd; g_ops.fmul += t_ops.fmul; g_ops.fdiv += t_ops.fdiv;
+    pthread_mutex_unlock(&g_ops_lock);
+    memset(&t_ops, 0, sizeof t_ops);
+}
+int orc_op_counts_take(orc_op_counts *out)
+{
+    ops_flush();
+    pthread_mutex_lock(&g_ops_lock);
+    if (out) *out = g_ops;
+    memset(&g_ops, 0, sizeof g_ops);
+    pthread_mutex_unlock(&g_ops_lock);
+    return 1;
+}
+#else
+#define OPS(field, n) ((void)0)
+static void ops_flush(void) {}
+int orc_op_counts_take(orc_op_counts *out)
+{
+    if (out) memset(out, 0, sizeof *out);
+    return 0; /* this build does not count */
+}
+#endif
+
+/* ===================================================================== */
 /* gfm:math restatement                                                   */
 /* ===================================================================== */
 
@@ -39,12 +81,13 @@ typedef struct { double c[3][3]; } M3;
 static inline V3 v3(double x, double y, double z) { V3 r = {x, y, z}; return r; }
 static inline V3 v3p(const double *p) { return v3(p[0], p[1], p[2]); }
 static inline void v3store(double *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
-static inline V3 vadd(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-static inline V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-static inline V3 vmul(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline V3 vadd(V3 a, V3 b) { OPS(dadd, 3); return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 vsub(V3 a, V3 b) { OPS(dadd, 3); return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 vmul(V3 a, double s) { OPS(dmul, 3); return v3(a.x * s, a.y * s, a.z * s); }
 static inline V3 vneg(V3 a) { return v3(-a.x, -a.y, -a.z); }
 static inline double vdot(V3 a, V3 b)
 {
+    OPS(dmul, 3); OPS(dadd, 3);
     double sum = 0;
     sum += a.x * b.x;
     sum += a.y * b.y;
@@ -53,19 +96,22 @@ static inline double vdot(V3 a, V3 b)
 }
 static inline V3 vcross(V3 a, V3 b)
 {
+    OPS(dmul, 6); OPS(dadd, 3);
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 static inline double vsqmag(V3 a)
 {
+    OPS(dmul, 3); OPS(dadd, 3);
     double s = 0;
     s += a.x * a.x;
     s += a.y * a.y;
     s += a.z * a.z;
     return s;
 }
-static inline double vmag(V3 a) { return sqrt(vsqmag(a)); }
+static inline double vmag(V3 a) { OPS(dsqrt, 1); return sqrt(vsqmag(a)); }
 static inline V3 vnormalized(V3 a)
 {
+    OPS(ddiv, 1); OPS(dmul, 3);
     double inv = 1 / vmag(a);
     return v3(a.x * inv, a.y * inv, a.z * inv);
 }
@@ -144,6 +190,7 @@ static inline double radians_(double x) { return x * 0x1.1df46a2529d39p-6; }
 /* mul(v, M): row vector x matrix — rt/imported_types.d:13-20 */
 static inline V3 mul_vm(V3 v, const double *m /* 9, row-major */)
 {
+    OPS(dmul, 9); OPS(dadd, 6);
     return v3(v.x * m[0] + v.y * m[3] + v.z * m[6],
               v.x * m[1] + v.y * m[4] + v.z * m[7],
               v.x * m[2] + v.y * m[5] + v.z * m[8]);
@@ -166,6 +213,7 @@ static inline V3 unproject_(V3 v, int a, int b, int c)
 /* reflect — rt/imported_types.d:62-67 */
 static inline V3 reflect_(V3 ray, V3 norm)
 {
+    OPS(dmul, 1); /* 2 * dot */
     V3 r = vsub(ray, vmul(norm, 2 * vdot(ray, norm)));
     return vnormalized(r);
 }
@@ -184,17 +232,18 @@ typedef struct { float r, g, b; } Col;
 static inline Col col(float r, float g, float b) { Col c = {r, g, b}; return c; }
 static inline Col colp(const float *p) { return col(p[0], p[1], p[2]); }
 /* opBinary + - * (Color) — rt/color.d:122-126 */
-static inline Col cadd(Col a, Col b) { return col(a.r + b.r, a.g + b.g, a.b + b.b); }
-static inline Col cmulc(Col a, Col b) { return col(a.r * b.r, a.g * b.g, a.b * b.b); }
+static inline Col cadd(Col a, Col b) { OPS(fadd, 3); return col(a.r + b.r, a.g + b.g, a.b + b.b); }
+static inline Col cmulc(Col a, Col b) { OPS(fmul, 3); return col(a.r * b.r, a.g * b.g, a.b * b.b); }
 /* opBinary * / (float) — rt/color.d:128-132; double arguments narrow first */
-static inline Col cmulf(Col a, float f) { return col(a.r * f, a.g * f, a.b * f); }
-static inline Col cdivf(Col a, float f) { return col(a.r / f, a.g / f, a.b / f); }
+static inline Col cmulf(Col a, float f) { OPS(fmul, 3); return col(a.r * f, a.g * f, a.b * f); }
+static inline Col cdivf(Col a, float f) { OPS(fdiv, 3); return col(a.r / f, a.g / f, a.b / f); }
 /* intensity — rt/color.d:141-144 */
-static inline float cintensity(Col a) { return (a.r + a.g + a.b) / 3; }
+static inline float cintensity(Col a) { OPS(fadd, 2); OPS(fdiv, 1); return (a.r + a.g + a.b) / 3; }
 /* adjustSaturation — rt/color.d:77-83 */
 static inline Col cadjust_saturation(Col c, float amount)
 {
     float mid = cintensity(c);
+    OPS(fmul, 6); OPS(fadd, 6);
     return col(c.r * amount + mid * (1 - amount), c.g * amount + mid * (1 - amount),
                c.b * amount + mid * (1 - amount));
 }
@@ -290,18 +339,20 @@ static inline Ray ray_project(Ray r, int a, int b, int c)
 /* util/array.d                                                           */
 /* ===================================================================== */
 
-typedef struct { ID *storage; size_t cap, n; } IDArray; /* MyArray!ID — util/array.d:3-64 */
+/* MyArray!ID — util/array.d:3-64.  The reference's array mallocs 16 entries (defaultInitialCapacity)
+ * and doubles; three of them per CsgOp.intersect.  Here the lists cannot outgrow that first block —
+ * findAllIntersections is capped at C2RT_MAX_CSG_HITS = 8 per child (see csg_find_all), so the
+ * concatenation holds at most 16 — and the storage is the caller's stack: same contents, same
+ * order, no allocator (2 KiB mallocs are above glibc's tcache limit and serialise the worker
+ * threads on the arena lock, which made the multi-core baseline an allocator benchmark). */
+#define IDA_CAP (2 * C2RT_MAX_CSG_HITS)
+typedef struct { ID storage[IDA_CAP]; size_t n; } IDArray;
 
 static void ida_push(IDArray *a, const ID *v)
 {
-    if (a->n >= a->cap) {
-        size_t nc = a->cap > 0 ? a->cap * 2 : 16; /* defaultInitialCapacity */
-        a->storage = (ID *)realloc(a->storage, nc * sizeof(ID));
-        a->cap = nc;
-    }
+    if (a->n >= IDA_CAP) abort(); /* unreachable: 8 + 8 */
     a->storage[a->n++] = *v;
 }
-static void ida_free(IDArray *a) { free(a->storage); a->storage = NULL; a->cap = a->n = 0; }
 
 /* sort (shell sort) — util/array.d:95-111; compare = opCmp on dist,
  * rt/intersectable.d:27-32.  The foreach index is taken by ref and rewound
@@ -340,6 +391,7 @@ static int plane_intersect(Scene *s, int32_t g, Ray ray, ID *data)
     double yDiff = ray.dir.y;
     double wantYDiff = ray.orig.y - y;
     double mult = wantYDiff / -yDiff;
+    OPS(dadd, 1); OPS(ddiv, 1);
     if (mult > data->dist) return 0;
     V3 p = vadd(ray.orig, vmul(ray.dir, mult));
     if (fabs(p.x) > limit || fabs(p.z) > limit) return 0;
@@ -364,9 +416,11 @@ static int sphere_intersect(Scene *s, int32_t g, Ray ray, ID *info)
     double B = 2 * vdot(H, ray.dir);
     double C = vsqmag(H) - R * R;
     double Dscr = B * B - 4 * A * C;
+    OPS(dmul, 5); OPS(dadd, 2);
     if (Dscr < 0) return 0;
     double x1 = (-B + sqrt(Dscr)) / (2 * A);
     double x2 = (-B - sqrt(Dscr)) / (2 * A);
+    OPS(dsqrt, 2); OPS(dadd, 2); OPS(dmul, 2); OPS(ddiv, 2);
     double sol = x2;
     if (sol < 0) sol = x1;
     if (sol < 0) return 0;
@@ -375,6 +429,9 @@ static int sphere_intersect(Scene *s, int32_t g, Ray ray, ID *info)
     info->p = vadd(ray.orig, vmul(ray.dir, sol));
     info->normal = vsub(info->p, center);
     info->normal = vnormalized(info->normal);
+    /* atan2, asin, cos, sin + their argument arithmetic (dNdx is computed by the reference although
+     * nothing on this path reads it) */
+    OPS(dlibm, 4); OPS(dadd, 8); OPS(ddiv, 3);
     double angle = atan2(info->p.z - center.z, info->p.x - center.x);
     info->u = (ORC_PI + angle) / (2 * ORC_PI);
     info->v = 1.0 - (ORC_PI / 2 + asin((info->p.y - center.y) / R)) / ORC_PI;
@@ -389,6 +446,7 @@ static int sphere_is_inside(Scene *s, int32_t g, V3 p)
 {
     V3 center = v3p(&s->geom_param[4 * g]);
     double R = s->geom_param[4 * g + 3];
+    OPS(dmul, 1);
     return vsqmag(vsub(center, p)) < R * R;
 }
 
@@ -397,14 +455,17 @@ static int cube_side(double cubeSide, Ray ray, V3 center, ID *data)
 {
     if (fabs(ray.dir.y) < 1e-9) return 0;
     double halfSide = cubeSide * 0.5;
+    OPS(dmul, 1);
     int found = 0;
     for (int side = -1; side <= 1; side += 2) {
         double yDiff = ray.dir.y;
         double wantYDiff = ray.orig.y - (center.y + side * halfSide);
         double mult = wantYDiff / -yDiff;
+        OPS(dmul, 1); OPS(dadd, 2); OPS(ddiv, 1);
         if (mult < 0) continue;
         if (mult > data->dist) continue;
         V3 p = vadd(ray.orig, vmul(ray.dir, mult));
+        OPS(dadd, 4); /* centre -+ halfSide, up to four (short-circuit: counted as written) */
         if (p.x < center.x - halfSide || p.x > center.x + halfSide ||
             p.z < center.z - halfSide || p.z > center.z + halfSide)
             continue;
@@ -415,6 +476,7 @@ static int cube_side(double cubeSide, Ray ray, V3 center, ID *data)
         data->dNdy = v3(0, 0, side);
         data->u = data->p.x - center.x;
         data->v = data->p.z - center.z;
+        OPS(dadd, 2);
         found = 1;
     }
     return found;
@@ -445,6 +507,7 @@ static int cube_is_inside(Scene *s, int32_t g, V3 p)
 {
     V3 center = v3p(&s->geom_param[4 * g]);
     double side = s->geom_param[4 * g + 3];
+    OPS(dadd, 3); OPS(dmul, 3);
     return fabs(p.x - center.x) <= side * 0.5 && fabs(p.y - center.y) <= side * 0.5 &&
            fabs(p.z - center.z) <= side * 0.5;
 }
@@ -472,6 +535,7 @@ static void csg_find_all(Scene *s, int32_t geom, Ray ray, IDArray *l)
         temp.dist = 1e99;
         if (!geom_intersect(s, geom, ray, &temp)) break;
         temp.dist += currentLength;
+        OPS(dadd, 1);
         currentLength = temp.dist;
         ray.orig = vadd(temp.p, vmul(ray.dir, 1e-6));
         ida_push(l, &temp);
@@ -483,7 +547,8 @@ static int csg_intersect_base(Scene *s, int32_t g, Ray ray, ID *data)
 {
     int32_t left = s->geom_child[2 * g + 0], right = s->geom_child[2 * g + 1];
     int type = s->geom_type[g];
-    IDArray leftData = {0}, rightData = {0}, allData = {0};
+    IDArray leftData, rightData, allData;
+    leftData.n = rightData.n = allData.n = 0;
     csg_find_all(s, left, ray, &leftData);
     csg_find_all(s, right, ray, &rightData);
     for (size_t i = 0; i < leftData.n; ++i) ida_push(&allData, &leftData.storage[i]);
@@ -505,9 +570,6 @@ static int csg_intersect_base(Scene *s, int32_t g, Ray ray, ID *data)
             break;
         }
     }
-    ida_free(&leftData);
-    ida_free(&rightData);
-    ida_free(&allData);
     return result;
 }
 
@@ -568,6 +630,7 @@ static int node_intersect(Scene *s, int32_t n, Ray ray, ID *data)
     double oldDist = data->dist;
     double rayDirLength = vmag(rc.dir);
     data->dist *= rayDirLength;
+    OPS(dmul, 1);
     rc.dir = vnormalized(rc.dir);
     if (!geom_intersect(s, s->node_geom[n], rc, data)) {
         data->dist = oldDist;
@@ -578,6 +641,7 @@ static int node_intersect(Scene *s, int32_t n, Ray ray, ID *data)
     data->dNdy = vnormalized(mul_vm(data->dNdy, T_M(t)));
     data->p = vadd(mul_vm(data->p, T_M(t)), v3p(T_OFF(t)));
     data->dist /= rayDirLength;
+    OPS(ddiv, 1);
     return 1;
 }
 
@@ -620,6 +684,7 @@ static Col bitmap_filtered_pixel(Scene *s, int32_t tex, float x, float y)
     uint64_t ty_next = (ty + 1) % height;
     float p = x - (float)tx;
     float q = y - (float)ty;
+    OPS(fadd, 2 + 4); OPS(fmul, 4); /* p, q; (1-p), (1-q) twice each; four weights */
 #define TEXEL(X, Y) colp(px + 3 * ((Y) * width + (X)))
     Col r = cmulf(TEXEL(tx, ty), (1.0f - p) * (1.0f - q));
     r = cadd(r, cmulf(TEXEL(tx_next, ty), p * (1.0f - q)));
@@ -637,6 +702,7 @@ static Col tex_color(Scene *s, int32_t tex, double u, double v)
         double size = s->tex_param[6 * tex];
         int32_t x = d2i_x86(floor(u / size));
         int32_t y = d2i_x86(floor(v / size));
+        OPS(ddiv, 2); OPS(dlibm, 2);
         int32_t white = (int32_t)((uint32_t)x + (uint32_t)y) % 2;
         return white ? colp(c + 3) : colp(c);
     }
@@ -644,6 +710,7 @@ static Col tex_color(Scene *s, int32_t tex, double u, double v)
         const float *cu = &s->tex_color[18 * tex], *cv = cu + 9;
         const double *fu = &s->tex_param[6 * tex], *fv = fu + 3;
         Col result = col(0, 0, 0);
+        OPS(dmul, 6); OPS(dlibm, 6);
         for (int i = 0; i < 3; ++i)
             result = cadd(result, cadd(cmulf(colp(cu + 3 * i), (float)sin(u * fu[i])),
                                        cmulf(colp(cv + 3 * i), (float)sin(v * fv[i]))));
@@ -655,6 +722,7 @@ static Col tex_color(Scene *s, int32_t tex, double u, double v)
         v *= scaling;
         u = u - floor(u);
         v = v - floor(v);
+        OPS(dmul, 2); OPS(dlibm, 2); OPS(dadd, 2); OPS(fmul, 2);
         float tx = (float)u * (float)s->tex_width[tex];
         float ty = (float)v * (float)s->tex_height[tex];
         return bitmap_filtered_pixel(s, tex, tx, ty);
@@ -700,6 +768,7 @@ static Col shade(Scene *s, int32_t shader, Ray ray, const ID *data, Counters *cn
                     if (cosTheta > 0) avgColor = cadd(avgColor, cmulf(baseLight, (float)cosTheta));
                     V3 R = reflect_(vneg(lightDir), N);
                     double cosGamma = vdot(R, vneg(ray.dir));
+                    if (cosGamma > 0) OPS(dlibm, 1); /* pow */
                     if (cosGamma > 0)
                         avgSpecular = cadd(avgSpecular,
                                            cmulf(cmulf(baseLight, (float)pow(cosGamma, s->shader_exponent[shader])),
@@ -838,6 +907,7 @@ static Ray screen_ray(const c2rt_camera_frame *cam, double x, double y, int offs
     result.orig = pos;
     V3 target = vadd(vadd(upLeft, vmul(vsub(upRight, upLeft), x / cam->frame_width)),
                      vmul(vsub(downLeft, upLeft), y / cam->frame_height));
+    OPS(ddiv, 2);
     result.dir = vsub(target, pos);
     result.dir = vnormalized(result.dir);
     if (offset != 0)
@@ -846,6 +916,9 @@ static Ray screen_ray(const c2rt_camera_frame *cam, double x, double y, int offs
 
     double cosTheta = vdot(result.dir, frontDir);
     double M = cam->focal_plane_dist / cosTheta;
+    /* M; unitDiscSample (rt/camera.d:258-269): U*2*PI, sin*rad, cos*rad, 2 x discMultiplier; sqrt; sin, cos;
+     * two uniform() draws (util/random.d:19-28: b - a, r / RAND_MAX, * delta, a +) */
+    OPS(ddiv, 1 + 2); OPS(dmul, 6 + 2); OPS(dsqrt, 1); OPS(dlibm, 2); OPS(dadd, 4);
     V3 T = vadd(result.orig, vmul(result.dir, M));
     /* unitDiscSample — rt/camera.d:258-269 */
     double u1 = rng_next(rng);
@@ -913,6 +986,9 @@ static Col render_sample(const RenderCtx *rc, double x, double y, int dx, int dy
         for (uint32_t i = 0; i < cam->num_samples; ++i) {
             rng.sample = i;
             rng.dim = 0;
+            /* x + uniform(0.0, 1.0) * dx, y + ... (rt/renderer.d:276-277), per eye */
+            OPS(ddiv, 2); OPS(dmul, 4); OPS(dadd, 6);
+            if (cam->stereo_separation != 0) { OPS(ddiv, 2); OPS(dmul, 4); OPS(dadd, 6); }
             if (cam->stereo_separation == 0) {
                 double jx = rng_next(&rng), jy = rng_next(&rng);
                 average = cadd(average, raytrace(rc->scene, screen_ray(cam, x + jx * dx, y + jy * dy, 0, &rng), cnt, tr));
@@ -994,6 +1070,7 @@ static void *worker(void *arg)
     }
     atomic_fetch_add(&job->primary, cnt.primary);
     atomic_fetch_add(&job->shadow, cnt.shadow);
+    ops_flush();
     return NULL;
 }
 
@@ -1082,6 +1159,7 @@ int orc_render_frame(const c2rt_scene_desc *scene, const c2rt_camera_frame *cam,
                 }
             }
         if (stats) { stats->primary_rays = cnt.primary; stats->shadow_rays = cnt.shadow; }
+        ops_flush();
         return C2RT_OK;
     }
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);

@@ -108,6 +108,17 @@ double orc_rng_uniform(uint64_t seed, uint64_t pixel, uint32_t tap,
  * libm-free so that the device produces the same bits. */
 void orc_lens_sincos2pi(double u, double *sn, double *cs);
 
+/* Algorithmic floating-point operation counts of the render path as the reference's source
+ * executes it; only the library built with -DORC_COUNT_OPS
+ * (oracle/libc2rt_oracle_count.so) tallies.  orc_op_counts_take copies the totals accumulated by
+ * orc_render_frame / orc_render_pixel calls since the last take and clears them; returns 1 if this
+ * build counts, 0 otherwise (all zeros). */
+typedef struct orc_op_counts {
+    uint64_t dadd, dmul, ddiv, dsqrt, dlibm; /* fp64: add/sub, mul, div, sqrt, libm calls */
+    uint64_t fadd, fmul, fdiv;               /* fp32 colour arithmetic */
+} orc_op_counts;
+int orc_op_counts_take(orc_op_counts *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,9 @@ import csv, json, os, sys, statistics
 from collections import defaultdict
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+workload = sys.argv[4] if len(sys.argv) > 4 else None   # also write profiles/traffic_<workload>.json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
 KERNEL = "render_kernel"
 summ = {"tag": tag, "kernel": None}
 
@@ -50,9 +53,31 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     d["write_bytes"] = c["WRITE_SIZE"] * 1024
     d["hbm_bytes_per_launch"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
 summ["derived"] = d
+summ["kernel_source_hash"] = kernel_source_hash()
 os.makedirs(dst, exist_ok=True)
 with open(os.path.join(dst, "%s_summary.json" % tag), "w") as f:
     json.dump(summ, f, indent=1)
 with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
     f.write(open(os.path.join(src, "trace", "trace_kernel_stats.csv")).read())
+if workload and "hbm_bytes_per_launch" in d and "SQ_INSTS_VALU" in c:
+    # the per-launch counts bench.py may combine with a live kernel time — only for the kernels hashed here
+    fetch, write = d["fetch_bytes"], d["write_bytes"]
+    tr_json = {
+        "workload": workload,
+        "kernel_source_hash": summ["kernel_source_hash"],
+        "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, averages over the timed launches)" % tag,
+        "fetch_bytes": fetch,
+        "write_bytes": write,
+        "hbm_bytes_per_launch_uncorrected": fetch + write,
+        # MI355X_MICROARCH.md, HBM section: gfx950 tallies 128-B read requests as 64 B -> FETCH_SIZE doubled; WRITE_SIZE as is
+        "hbm_bytes_per_launch": 2 * fetch + write,
+        "valu_insts_per_launch": c["SQ_INSTS_VALU"],
+        "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
+        "valu_busy_fraction": d.get("valu_active_over_busy"),
+        "lane_utilisation": d.get("lane_utilisation"),
+        "valu_insts_per_wave": d.get("valu_insts_per_wave"),
+        "kernel_avg_us": summ["avg_duration_us_timed"],
+    }
+    with open(os.path.join(dst, "traffic_%s.json" % workload), "w") as f:
+        json.dump(tr_json, f, indent=1)
 print(json.dumps(summ, indent=1))

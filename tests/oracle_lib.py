@@ -76,6 +76,45 @@ def lib():
     return _lib
 
 
+class OpCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("dadd", "dmul", "ddiv", "dsqrt", "dlibm", "fadd", "fmul", "fdiv")]
+
+
+_count_lib = None
+
+
+def op_counts(desc, cam, opts, n_threads=0):
+    """Algorithmic floating-point operations of one oracle frame (the counting build,
+    oracle/libc2rt_oracle_count.so): dict of fp64 add/mul/div/sqrt/libm and fp32 add/mul/div tallies
+    plus "fp64" = their fp64 sum (div, sqrt and libm calls counted as one each)."""
+    global _count_lib
+    if _count_lib is None:
+        path = os.path.join(ROOT, "oracle", "libc2rt_oracle_count.so")
+        if not os.path.exists(path):
+            raise RuntimeError("counting oracle not built: run `make oracle/libc2rt_oracle_count.so`")
+        L = C.CDLL(path)
+        L.orc_render_frame.argtypes = [C.POINTER(SceneDesc), C.POINTER(CameraFrame), C.POINTER(RenderOpts), C.c_void_p, C.c_uint32, C.POINTER(RayStats)]
+        L.orc_render_frame.restype = C.c_int
+        L.orc_op_counts_take.argtypes = [C.POINTER(OpCounts)]
+        L.orc_op_counts_take.restype = C.c_int
+        _count_lib = L
+    L = _count_lib
+    out = np.zeros((local_rows(opts), opts.width, 3), dtype=np.float32)
+    st = RayStats()
+    oc = OpCounts()
+    L.orc_op_counts_take(C.byref(oc))  # clear
+    rc = L.orc_render_frame(desc, C.byref(cam), C.byref(opts), out.ctypes.data_as(C.c_void_p), n_threads, C.byref(st))
+    if rc != 0:
+        raise RuntimeError("orc_render_frame (counting build) status %d" % rc)
+    if L.orc_op_counts_take(C.byref(oc)) != 1:
+        raise RuntimeError("libc2rt_oracle_count.so was built without -DORC_COUNT_OPS")
+    d = {n: int(getattr(oc, n)) for n, _ in OpCounts._fields_}
+    d["fp64"] = d["dadd"] + d["dmul"] + d["ddiv"] + d["dsqrt"] + d["dlibm"]
+    d["fp32"] = d["fadd"] + d["fmul"] + d["fdiv"]
+    d["primary_rays"], d["shadow_rays"] = int(st.primary_rays), int(st.shadow_rays)
+    return d, out
+
+
 def vec3(x, y, z):
     return (C.c_double * 3)(x, y, z)
 

@@ -1,0 +1,54 @@
+"""The counting build of the oracle (oracle/libc2rt_oracle_count.so, -DORC_COUNT_OPS): the
+algorithmic floating-point operation count bench.py's roofline.flops rests on."""
+import os
+
+import numpy as np
+
+import chess2rt_amd as c2
+import oracle_lib as orc
+from golden_configs import SCENES, load_config
+
+
+def test_counting_build_renders_the_same_frame_and_counts_deterministically():
+    scene, cam, opts = load_config("lecture5_333x217_t4")
+    ref = orc.render_frame(scene.desc, cam, opts, 2)
+    ops1, img1 = orc.op_counts(scene.desc, cam, opts, 1)
+    ops4, img4 = orc.op_counts(scene.desc, cam, opts, 4)
+    assert np.array_equal(img1, ref) and np.array_equal(img4, ref)
+    assert ops1 == ops4                       # thread-local tallies, flushed once per worker
+    assert ops1["primary_rays"] == 333 * 217 * 4
+    assert ops1["fp64"] == ops1["dadd"] + ops1["dmul"] + ops1["ddiv"] + ops1["dsqrt"] + ops1["dlibm"]
+    # lecture5 has spheres, a cube, a CsgDiff, Phong and bitmap textures: every class of operation occurs
+    assert all(ops1[k] > 0 for k in ("dadd", "dmul", "ddiv", "dsqrt", "dlibm", "fadd", "fmul", "fdiv"))
+
+
+def test_sky_rays_cost_exactly_what_the_source_says():
+    """lecture4 with the camera pitched up: every ray misses the one Plane node.  Per ray the
+    reference executes getScreenRay (rt/camera.d:123-147), Node.intersect's transform of the ray
+    (rt/node.d:28-36) and Plane.intersect's first rejection (rt/geometry.d:33-34, no arithmetic):
+      getScreenRay: 2 vector subs + 2 divs + 2 vector*scalar + 2 vector adds + (target - pos) + normalize
+      Node.intersect: (orig - offset), 2 row-vector x matrix products, magnitude, dist *= len, normalize
+    = 39 fp64 add/sub, 40 mul, 4 div, 3 sqrt, no libm, no colour arithmetic."""
+    scene = c2.parseSceneFromFile(os.path.join(SCENES, "lecture4.sdl"))
+    scene.setFrameSize(64, 48)
+    scene.setAA(False)
+    cam = scene.camera
+    cam.pitch = 80.0
+    scene.camera = cam
+    frame = scene.beginFrame()
+    opts = scene.renderOpts()
+    ops, img = orc.op_counts(scene.desc, frame, opts, 2)
+    n = 64 * 48
+    assert not img.any() and ops["shadow_rays"] == 0 and ops["primary_rays"] == n
+    assert (ops["dadd"], ops["dmul"], ops["ddiv"], ops["dsqrt"], ops["dlibm"]) == (39 * n, 40 * n, 4 * n, 3 * n, 0)
+    assert ops["fp32"] == 0
+
+
+def test_plain_build_reports_that_it_does_not_count():
+    import ctypes as C
+
+    L = orc.lib()
+    L.orc_op_counts_take.argtypes = [C.POINTER(orc.OpCounts)]
+    L.orc_op_counts_take.restype = C.c_int
+    oc = orc.OpCounts()
+    assert L.orc_op_counts_take(C.byref(oc)) == 0 and oc.dadd == 0
