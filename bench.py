@@ -91,7 +91,7 @@ def cpu_baseline(c2, scene_file, width, height, taps, dof, rays_per_frame, budge
         return sc, sc.beginFrame(), sc.renderOpts(taps=taps)
 
     scene, cam, opts = load(width, height)
-    cores = len(os.sched_getaffinity(0))
+    cores, affinity, quota = usable_cores()
     times = []
     t_all = time.time()
     oracle_lib.render_frame(scene.desc, cam, opts, cores)  # warm-up
@@ -126,7 +126,30 @@ def cpu_baseline(c2, scene_file, width, height, taps, dof, rays_per_frame, budge
                        "sample": "1 frame of the same scene and taps at %dx%d (1/16 of the rays), 1 thread" % (sw, sh)},
         "scaling_vs_one_thread": value / one,
         "cpu_model": cpu_model(),
+        "cores_note": "threads = min(affinity mask %d, cgroup CPU quota %s)" % (affinity, "%.1f" % quota if quota else "none"),
     }, ops
+
+
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box hands a 1-GPU job a share of its cores; threads beyond the quota only get throttled)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(math.ceil(quota))))
+    return n, len(os.sched_getaffinity(0)), quota
 
 
 def cpu_model():

@@ -110,12 +110,23 @@ def parseSceneFromFile(path):
 
 
 class Context:
-    """One GPU context (c2rt_ctx).  Raises if no GPU is usable."""
+    """One GPU context (c2rt_ctx).  Raises if no GPU is usable.
 
-    def __init__(self, device=-1):
+    ``Context(device)``: one device (c2rt_init).  ``Context(devices=[...])``: ONE context over several
+    device slots of this process (c2rt_init_multi; ids may repeat, ``devices=0`` = every visible GPU):
+    host-output frames are dealt to the slots in interleaved strips, device-output frames are stored by
+    every slot straight into the lead device's frame."""
+
+    def __init__(self, device=-1, devices=None):
         self._lib = _abi.load_library()
         h = C.c_void_p()
-        st = self._lib.c2rt_init(int(device), C.byref(h))
+        if devices is None:
+            st = self._lib.c2rt_init(int(device), C.byref(h))
+        elif isinstance(devices, int):
+            st = self._lib.c2rt_init_multi(int(devices), None, C.byref(h))
+        else:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            st = self._lib.c2rt_init_multi(len(devices), ids, C.byref(h))
         self._h = h if h.value else None
         if st != _abi.OK:
             msg = self._lib.c2rt_last_error(self._h).decode() if self._h else ""
@@ -142,6 +153,14 @@ class Context:
     def _check(self, st):
         if st != _abi.OK:
             raise C2rtError(st, self._lib.c2rt_last_error(self._h).decode(errors="replace"))
+
+    @property
+    def deviceCount(self):
+        return int(self._lib.c2rt_device_count(self._h))
+
+    @property
+    def sceneGeneration(self):
+        return int(self._lib.c2rt_scene_generation(self._h))
 
     def uploadScene(self, desc):
         """desc: POINTER(SceneDesc) or SceneDesc."""

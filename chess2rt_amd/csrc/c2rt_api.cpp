@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -27,6 +28,12 @@ constexpr int kMaxChunks = 8;      /* row chunks of a host-output frame */
 
 struct c2rt_ctx {
     int device = 0;
+    /* c2rt_init_multi: the further device slots of this (lead) context, each a complete
+     * single-device context of its own; empty for c2rt_init */
+    std::vector<c2rt_ctx *> peers;
+    bool peer_mapped = true;       /* (peer slot) can store into the lead device's memory */
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr; /* cross-device ordering of device-output frames */
+    uint64_t scene_gen = 0;        /* c2rt_scene_generation */
     std::string err;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;              /* D2H of finished chunks */
@@ -486,6 +493,8 @@ int c2rt_init(int device, c2rt_ctx **out)
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < kMaxChunks; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chunk_done[i], hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counters), 2 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->probe), sizeof(c2rt_trace_result)));
     uint8_t lut[4097];
@@ -495,10 +504,56 @@ int c2rt_init(int device, c2rt_ctx **out)
     return C2RT_OK;
 }
 
+int c2rt_init_multi(int device_count_or_0, const int *device_ids, c2rt_ctx **out)
+{
+    if (!out) return C2RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return C2RT_ERR_NO_DEVICE;
+    if (device_count_or_0 < 0 || device_count_or_0 > 64) return C2RT_ERR_INVALID_ARG;
+    const int n = device_count_or_0 == 0 ? visible : device_count_or_0;
+    std::vector<int> ids(n);
+    for (int i = 0; i < n; ++i) {
+        ids[i] = device_ids ? device_ids[i] : i;
+        if (ids[i] < 0 || ids[i] >= visible) return C2RT_ERR_NO_DEVICE;
+    }
+    c2rt_ctx *lead = nullptr;
+    int st = c2rt_init(ids[0], &lead);
+    *out = lead;
+    if (st != C2RT_OK) return st;
+    for (int i = 1; i < n; ++i) {
+        c2rt_ctx *peer = nullptr;
+        st = c2rt_init(ids[i], &peer);
+        if (peer) lead->peers.push_back(peer);
+        if (st != C2RT_OK) return fail(lead, st, "device slot %d (HIP device %d): %s", i, ids[i], peer ? peer->err.c_str() : "init failed");
+        if (ids[i] != ids[0]) {
+            /* the slot's kernels store into the lead device's frame (c2rt_render_frame_device) */
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, ids[i], ids[0]) != hipSuccess || !can) {
+                peer->peer_mapped = false;
+            } else {
+                const hipError_t e = hipDeviceEnablePeerAccess(ids[0], 0); /* current device = ids[i] (c2rt_init) */
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peer->peer_mapped = false;
+                (void)hipGetLastError();
+            }
+        }
+    }
+    HIP_TRY(lead, hipSetDevice(lead->device));
+    return C2RT_OK;
+}
+
+int c2rt_device_count(const c2rt_ctx *ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
+
+uint64_t c2rt_scene_generation(const c2rt_ctx *ctx) { return ctx && ctx->has_scene ? ctx->scene_gen : 0; }
+
 void c2rt_destroy(c2rt_ctx *ctx)
 {
     if (!ctx) return;
+    for (c2rt_ctx *p : ctx->peers) c2rt_destroy(p);
+    ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
+    if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
+    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     for (hipEvent_t e : ctx->chunk_done)
@@ -511,7 +566,27 @@ void c2rt_destroy(c2rt_ctx *ctx)
     delete ctx;
 }
 
+static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s);
+
 int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *s)
+{
+    static std::atomic<uint64_t> next_gen{1};
+    if (!ctx) return C2RT_ERR_INVALID_ARG;
+    int st = upload_one(ctx, s);
+    /* every device slot holds its own copy of the (small) tables and textures */
+    for (size_t i = 0; i < ctx->peers.size() && st == C2RT_OK; ++i) {
+        st = upload_one(ctx->peers[i], s);
+        if (st != C2RT_OK) {
+            ctx->has_scene = false;
+            return fail(ctx, st, "device slot %zu: %s", i + 1, ctx->peers[i]->err.c_str());
+        }
+    }
+    if (st == C2RT_OK) ctx->scene_gen = next_gen.fetch_add(1);
+    if (!ctx->peers.empty()) (void)hipSetDevice(ctx->device);
+    return st;
+}
+
+static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
 {
     if (!ctx) return C2RT_ERR_INVALID_ARG;
     if (!s) return fail(ctx, C2RT_ERR_INVALID_ARG, "null scene");
@@ -868,6 +943,150 @@ static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2r
     return C2RT_OK;
 }
 
+static int ensure_staging(c2rt_ctx *c, size_t floats)
+{
+    if (floats > c->frame_floats) {
+        if (c->frame) { (void)hipFree(c->frame); c->frame = nullptr; c->frame_floats = 0; }
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->frame), floats * sizeof(float)));
+        c->frame_floats = floats;
+    }
+    return C2RT_OK;
+}
+
+/* Interleaved strips of a multi-device context: kTileH rows (one tile row) — the finest deal the
+ * kernel's tiling allows, which balances the sky / floor / object mix best. */
+constexpr uint32_t kMultiStrip = kTileH;
+
+/* Host-output frame of a MULTI-DEVICE context (c2rt_init_multi): slot d renders strips d, d+G, ...
+ * into its own staging buffer and copies them straight into the caller's frame with ONE strided 2-D
+ * copy (row = one strip, destination pitch = G strips) over its own PCIe link — every device's copy
+ * engine works in parallel and nothing is assembled on a device.  (RGB32: each slot encodes first.) */
+static int render_to_host_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_rgb,
+                                uint32_t *out_rgb32, const volatile uint8_t *stop_flag)
+{
+    const uint32_t G = 1u + (uint32_t)ctx->peers.size();
+    const uint32_t sh = kMultiStrip, H = opts->height, W = opts->width;
+    const uint32_t n_strips = (H + sh - 1) / sh, rem = H % sh; /* rem > 0: the last strip is partial */
+    char *dst = out_rgb ? reinterpret_cast<char *>(out_rgb) : reinterpret_cast<char *>(out_rgb32);
+    const size_t px_bytes = out_rgb ? 3 * sizeof(float) : sizeof(uint32_t);
+    const size_t strip_bytes = (size_t)sh * W * px_bytes;
+    const KernelVariant variant = variant_of(ctx, cam);
+    ctx->counters_valid = false;
+    int st = C2RT_OK;
+    bool cancelled = false;
+    uint32_t launched = 0;
+    for (uint32_t d = 0; d < G && st == C2RT_OK; ++d) {
+        c2rt_ctx *c = d == 0 ? ctx : ctx->peers[d - 1];
+        if (stop_flag && *stop_flag) { cancelled = true; break; }
+        launched = d + 1;
+        c2rt_render_opts o = *opts;
+        o.strip_height = sh;
+        o.strip_rank = d;
+        o.strip_world = G;
+        RenderParams p;
+        fill_params(c, cam, &o, p);
+        const uint32_t rows = p.local_rows;
+        if (rows == 0) continue;
+        if (hipSetDevice(c->device) != hipSuccess) { st = fail(ctx, C2RT_ERR_HIP, "hipSetDevice(%d)", c->device); break; }
+        const size_t px = (size_t)rows * W;
+        if ((st = ensure_staging(c, px * 3 + (out_rgb32 ? px : 0))) != C2RT_OK) { st = fail(ctx, st, "slot %u: %s", d, c->err.c_str()); break; }
+        p.out = c->frame;
+        if (opts->count_rays) {
+            if (hipMemsetAsync(c->counters, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) { st = fail(ctx, C2RT_ERR_HIP, "counter reset"); break; }
+            p.ray_counters = c->counters;
+        }
+        int e = launch_render(p, variant, c->stream);
+        if (e != 0) { st = fail(ctx, C2RT_ERR_HIP, "render kernel launch (slot %u): %s", d, hipGetErrorString((hipError_t)e)); break; }
+        const char *src = reinterpret_cast<const char *>(c->frame);
+        if (out_rgb32) {
+            uint32_t *packed = reinterpret_cast<uint32_t *>(c->frame + px * 3);
+            e = launch_encode_rgb32(c->frame, packed, px, c->srgb_lut, c->stream);
+            if (e != 0) { st = fail(ctx, C2RT_ERR_HIP, "encode launch (slot %u): %s", d, hipGetErrorString((hipError_t)e)); break; }
+            src = reinterpret_cast<const char *>(packed);
+        }
+        /* this slot's strips: d, d+G, ...; all full except possibly the frame's last strip */
+        const uint32_t mine = (n_strips - d + G - 1) / G;
+        const bool owns_partial = rem != 0 && (n_strips - 1) % G == d;
+        const uint32_t full = owns_partial ? mine - 1 : mine;
+        hipError_t he = hipSuccess;
+        if (full)
+            he = hipMemcpy2DAsync(dst + (size_t)d * strip_bytes, (size_t)G * strip_bytes, src, strip_bytes, strip_bytes, full,
+                                  hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess && owns_partial)
+            he = hipMemcpyAsync(dst + (size_t)(n_strips - 1) * strip_bytes, src + (size_t)full * strip_bytes, (size_t)rem * W * px_bytes,
+                                hipMemcpyDeviceToHost, c->stream);
+        if (he != hipSuccess) st = fail(ctx, C2RT_ERR_HIP, "strip copy (slot %u): %s", d, hipGetErrorString(he));
+    }
+    for (uint32_t d = 0; d < launched; ++d) {
+        c2rt_ctx *c = d == 0 ? ctx : ctx->peers[d - 1];
+        (void)hipSetDevice(c->device);
+        const hipError_t he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess && st == C2RT_OK) st = fail(ctx, C2RT_ERR_HIP, "slot %u: %s", d, hipGetErrorString(he));
+    }
+    (void)hipSetDevice(ctx->device);
+    if (st != C2RT_OK) return st;
+    if (cancelled) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested during the frame");
+    if (opts->count_rays) {
+        ctx->counters_valid = true;
+        ctx->counters_stream = ctx->stream;
+    }
+    return C2RT_OK;
+}
+
+/* Device-output frame of a multi-device context: every slot's kernel stores its strips straight
+ * into `out_dev` on the lead device (RenderParams::frame_rows; peers reach it over xGMI through
+ * peer access).  Ordered on the caller's stream: the peers start after what that stream has queued
+ * so far (they overwrite the frame) and the stream continues after the last peer kernel. */
+static int render_device_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_dev,
+                               hipStream_t stream)
+{
+    const uint32_t G = 1u + (uint32_t)ctx->peers.size();
+    for (c2rt_ctx *c : ctx->peers)
+        if (!c->peer_mapped)
+            return fail(ctx, C2RT_ERR_UNSUPPORTED, "HIP device %d cannot map device %d's memory: use the host-output entry points", c->device, ctx->device);
+    const KernelVariant variant = variant_of(ctx, cam);
+    ctx->counters_valid = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_ready, stream));
+    for (uint32_t d = 0; d < G; ++d) {
+        c2rt_ctx *c = d == 0 ? ctx : ctx->peers[d - 1];
+        c2rt_render_opts o = *opts;
+        o.strip_height = kMultiStrip;
+        o.strip_rank = d;
+        o.strip_world = G;
+        RenderParams p;
+        fill_params(c, cam, &o, p);
+        p.out = out_dev;
+        p.frame_rows = 1;
+        HIP_TRY(ctx, hipSetDevice(c->device));
+        hipStream_t s = d == 0 ? stream : c->stream;
+        if (d != 0) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_ready, 0));
+        if (opts->count_rays) {
+            HIP_TRY(ctx, hipMemsetAsync(c->counters, 0, 2 * sizeof(unsigned long long), s));
+            p.ray_counters = c->counters;
+        }
+        if (p.local_rows) {
+            const int e = launch_render(p, variant, s);
+            if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch (slot %u): %s", d, hipGetErrorString((hipError_t)e));
+        }
+        if (d != 0) HIP_TRY(ctx, hipEventRecord(c->ev_done, s));
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (c2rt_ctx *c : ctx->peers) HIP_TRY(ctx, hipStreamWaitEvent(stream, c->ev_done, 0));
+    if (opts->count_rays) {
+        ctx->counters_valid = true;
+        ctx->counters_stream = stream;
+    }
+    return C2RT_OK;
+}
+
+static int check_multi_opts(c2rt_ctx *ctx, const c2rt_render_opts *opts)
+{
+    if (!ctx->peers.empty() && opts->strip_world > 1)
+        return fail(ctx, C2RT_ERR_INVALID_ARG, "a multi-device context shards the frame itself: strip_world must be <= 1");
+    return C2RT_OK;
+}
+
 uint32_t c2rt_local_rows(const c2rt_render_opts *opts)
 {
     if (!opts) return 0;
@@ -881,6 +1100,8 @@ int c2rt_render_frame_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const 
     int st = check_frame_args(ctx, cam, opts);
     if (st != C2RT_OK) return st;
     if (!out_rgb_dev) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
+    if ((st = check_multi_opts(ctx, opts)) != C2RT_OK) return st;
+    if (!ctx->peers.empty()) return render_device_multi(ctx, cam, opts, out_rgb_dev, static_cast<hipStream_t>(hip_stream));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return render_device(ctx, cam, opts, out_rgb_dev, static_cast<hipStream_t>(hip_stream));
 }
@@ -893,13 +1114,10 @@ int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
     if (!out_rgb) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
     /* isStopReq() before the pass — rt/renderer.d:129 */
     if (stop_flag && *stop_flag) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested before the frame");
+    if ((st = check_multi_opts(ctx, opts)) != C2RT_OK) return st;
+    if (!ctx->peers.empty()) return render_to_host_multi(ctx, cam, opts, out_rgb, nullptr, stop_flag);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t floats = (size_t)c2rt_local_rows(opts) * opts->width * 3;
-    if (floats > ctx->frame_floats) {
-        if (ctx->frame) { (void)hipFree(ctx->frame); ctx->frame = nullptr; ctx->frame_floats = 0; }
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->frame), floats * sizeof(float)));
-        ctx->frame_floats = floats;
-    }
+    if ((st = ensure_staging(ctx, (size_t)c2rt_local_rows(opts) * opts->width * 3)) != C2RT_OK) return st;
     return render_to_host(ctx, cam, opts, out_rgb, nullptr, stop_flag);
 }
 
@@ -908,9 +1126,18 @@ int c2rt_pin_host_buffer(c2rt_ctx *ctx, float *out_rgb, size_t bytes)
     if (!ctx) return C2RT_ERR_INVALID_ARG;
     if (!out_rgb || bytes == 0) return fail(ctx, C2RT_ERR_INVALID_ARG, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (const auto &pb : ctx->pinned)
-        if (pb.first == out_rgb) return C2RT_OK;
-    HIP_TRY(ctx, hipHostRegister(out_rgb, bytes, hipHostRegisterDefault));
+    for (size_t i = 0; i < ctx->pinned.size(); ++i)
+        if (ctx->pinned[i].first == out_rgb) {
+            if (ctx->pinned[i].second == bytes) return C2RT_OK;
+            /* the same address with another size (a re-allocated frame buffer): register afresh, so that
+             * the recorded range is exactly what is page-locked */
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+            HIP_TRY(ctx, hipHostUnregister(out_rgb));
+            ctx->pinned.erase(ctx->pinned.begin() + (long)i);
+            break;
+        }
+    /* portable: page-locked for every device slot of a multi-device context */
+    HIP_TRY(ctx, hipHostRegister(out_rgb, bytes, hipHostRegisterPortable));
     ctx->pinned.emplace_back(out_rgb, bytes);
     return C2RT_OK;
 }
@@ -939,6 +1166,14 @@ int c2rt_get_ray_stats(c2rt_ctx *ctx, c2rt_ray_stats *out)
     HIP_TRY(ctx, hipMemcpy(h, ctx->counters, sizeof h, hipMemcpyDeviceToHost));
     out->primary_rays = h[0];
     out->shadow_rays = h[1];
+    for (c2rt_ctx *c : ctx->peers) { /* every slot counted its own strips */
+        HIP_TRY(ctx, hipSetDevice(c->device));
+        HIP_TRY(ctx, hipStreamSynchronize(c->stream));
+        HIP_TRY(ctx, hipMemcpy(h, c->counters, sizeof h, hipMemcpyDeviceToHost));
+        out->primary_rays += h[0];
+        out->shadow_rays += h[1];
+    }
+    if (!ctx->peers.empty()) HIP_TRY(ctx, hipSetDevice(ctx->device));
     return C2RT_OK;
 }
 
@@ -1004,15 +1239,12 @@ int c2rt_render_frame_rgb32(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c
     if (st != C2RT_OK) return st;
     if (!out_rgb32) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
     if (stop_flag && *stop_flag) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested before the frame");
+    if ((st = check_multi_opts(ctx, opts)) != C2RT_OK) return st;
+    if (!ctx->peers.empty()) return render_to_host_multi(ctx, cam, opts, nullptr, out_rgb32, stop_flag);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t pixels = (size_t)c2rt_local_rows(opts) * opts->width;
     /* staging: float frame followed by the packed frame */
-    const size_t floats = pixels * 3 + pixels;
-    if (floats > ctx->frame_floats) {
-        if (ctx->frame) { (void)hipFree(ctx->frame); ctx->frame = nullptr; ctx->frame_floats = 0; }
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->frame), floats * sizeof(float)));
-        ctx->frame_floats = floats;
-    }
+    if ((st = ensure_staging(ctx, pixels * 3 + pixels)) != C2RT_OK) return st;
     return render_to_host(ctx, cam, opts, nullptr, out_rgb32, stop_flag);
 }
 

@@ -145,6 +145,10 @@ struct RenderParams {
     uint32_t strip_height, strip_rank, strip_world;
     uint32_t local_rows;           /* rows this launch renders */
     uint32_t row_offset;           /* first local row of this launch (chunked host-output renders) */
+    /* 0: `out` is this rank's compact strip buffer, indexed by LOCAL row.  1: `out` is the whole
+     * frame, indexed by FRAME row — the devices of a multi-device context store their strips straight
+     * into the lead device's frame over xGMI (peer-mapped): no gather buffer, no de-interleave pass. */
+    uint32_t frame_rows;
     /* Per-frame screen-space culling of PRIMARY rays (host-computed, c2rt_api.cpp):
      * the pixel rectangle [x0, x1) x [y0, y1) outside of which no ray through a
      * sample of this frame can reach node n's padded bounding box.  n_cull = 0

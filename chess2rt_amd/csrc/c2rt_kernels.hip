@@ -1278,7 +1278,7 @@ DEV void render_body(const RenderParams &P)
     }
     if (ntaps > 1) accum = accum / (float)ntaps; /* `accum / 5`: Color / float */
 
-    float *px = P.out + ((size_t)lr * P.width + x) * 3;
+    float *px = P.out + ((size_t)(P.frame_rows ? y : lr) * P.width + x) * 3;
     px[0] = accum.r;
     px[1] = accum.g;
     px[2] = accum.b;

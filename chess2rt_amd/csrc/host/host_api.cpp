@@ -14,7 +14,8 @@ using namespace c2rt::host;
 struct c2rt_host_scene {
     std::unique_ptr<Scene> scene;
     const c2rt_scene_desc *desc = nullptr; // cached flat view
-    c2rt_ctx *uploaded_to = nullptr;       // context that holds these tables
+    c2rt_ctx *uploaded_to = nullptr;       // context these tables were last uploaded to ...
+    uint64_t uploaded_gen = 0;             // ... and the generation that upload got (c2rt_scene_generation)
     std::thread render_thread;
     int async_status = C2RT_OK;
 };
@@ -49,10 +50,16 @@ struct Renderer {
 
     int ensureUploaded()
     {
-        if (hs->uploaded_to == ctx && hs->desc) return C2RT_OK;
+        // A context holds ONE scene.  Skip the upload only if what the context holds now is this
+        // scene's own upload: the generation is process-unique, so another scene uploaded to the same
+        // context since (a second Renderer, a direct c2rt_upload_scene), or a new context allocated at
+        // the address of a destroyed one, both show up as a different generation.
+        if (hs->desc && hs->uploaded_to == ctx && hs->uploaded_gen != 0 && c2rt_scene_generation(ctx) == hs->uploaded_gen)
+            return C2RT_OK;
         hs->desc = hs->scene->flatten();
         const int st = c2rt_upload_scene(ctx, hs->desc);
-        if (st == C2RT_OK) hs->uploaded_to = ctx;
+        hs->uploaded_to = st == C2RT_OK ? ctx : nullptr;
+        hs->uploaded_gen = st == C2RT_OK ? c2rt_scene_generation(ctx) : 0;
         return st;
     }
 

@@ -219,6 +219,28 @@ typedef struct c2rt_ctx c2rt_ctx;
 /* device < 0: use the current HIP device.  Fails with C2RT_ERR_NO_DEVICE when
  * no GPU is visible: there is NO CPU fallback in this library. */
 int c2rt_init(int device, c2rt_ctx **out);
+
+/* ONE context over several GPUs of this process — SURVEY.md 8(b)'s
+ * `c2rt_init(int device_count_or_0, ...)`: what a single-process host like the
+ * reference (one render thread fanning out, rt/renderer.d:23-44,133-142) needs
+ * to use a whole node.  device_count_or_0 = 0 opens every visible GPU;
+ * `device_ids` (nullable) names the HIP device of each slot — entries may
+ * repeat, which runs several slots on one GPU (how a 1-GPU box exercises this
+ * path).  Slot 0 is the lead device.  On such a context
+ *   - c2rt_upload_scene replicates the tables on every device;
+ *   - c2rt_render_frame / c2rt_render_frame_rgb32 deal interleaved 8-row strips
+ *     to the devices (opts->strip_world must be <= 1) and every device copies
+ *     its finished strips straight into the caller's host frame over its own
+ *     PCIe link (strided 2-D copies; pin the buffer with c2rt_pin_host_buffer);
+ *   - c2rt_render_frame_device: `out_rgb_dev` lives on the lead device and the
+ *     other devices' kernels store their strips straight into it over xGMI
+ *     (peer access) — no gather buffer, no de-interleave pass;
+ *   - c2rt_render_pixel and the strip / encode helpers run on the lead device.
+ * C2RT_ERR_NO_DEVICE when a device id is out of range; C2RT_ERR_UNSUPPORTED
+ * from c2rt_render_frame_device when a device cannot peer-map the lead. */
+int c2rt_init_multi(int device_count_or_0, const int *device_ids, c2rt_ctx **out);
+/* number of device slots of the context (1 for c2rt_init) */
+int c2rt_device_count(const c2rt_ctx *ctx);
 void c2rt_destroy(c2rt_ctx *ctx);
 const char *c2rt_last_error(const c2rt_ctx *ctx);
 const char *c2rt_status_string(int status);
@@ -229,6 +251,11 @@ uint32_t c2rt_abi_version(void);
 /* Validates and copies the tables into HBM.  Replaces the implicit "scene is
  * GC memory shared with the render thread" of rt/renderer.d:39-40. */
 int c2rt_upload_scene(c2rt_ctx *ctx, const c2rt_scene_desc *scene);
+/* Identity of the tables the context holds now: a process-wide counter value
+ * assigned by each successful c2rt_upload_scene (never reused, never 0; 0 = no
+ * scene).  A host-side scene object remembers the value of ITS upload and
+ * re-uploads when the context has moved on to another scene. */
+uint64_t c2rt_scene_generation(const c2rt_ctx *ctx);
 
 /* ---- rendering ---------------------------------------------------------- */
 

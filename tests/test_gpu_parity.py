@@ -566,6 +566,86 @@ def test_plain_c_caller_matches_oracle(tmp_path):
     assert "beyond_tol 0" in p.stdout
 
 
+@pytest.mark.parametrize("slots,w,h", [(2, 203, 149), (3, 333, 217), (8, 640, 360)])
+def test_multi_device_context_from_plain_c(tmp_path, slots, w, h):
+    """c2rt_init_multi (SURVEY.md 8(b) `device_count_or_0`) driven from a C program: N device slots (all on
+    HIP device 0 here) deal the frame in interleaved 8-row strips and copy them straight into the host
+    frame; float (pageable, pinned) and RGB32 frames equal the one-device frames bit for bit, the ray
+    counts add up, the one-device frame matches the oracle."""
+    import subprocess
+
+    from test_abi_exports import ROOT, _build_c_program
+
+    exe = str(tmp_path / "c_multi_check")
+    _build_c_program(os.path.join(ROOT, "tests", "c_multi_check.c"), exe, with_oracle=True)
+    p = subprocess.run([exe, str(w), str(h), str(slots)], capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "differ 0 differ32 0 beyond_tol 0" in p.stdout
+
+
+def test_multi_device_context_device_output_and_modes():
+    """The same through the Python face, incl. the device-output entry point (every slot's kernel stores
+    its strips straight into the lead device's frame — RenderParams::frame_rows), 1/4/5 taps, depth of
+    field, prepassOnly and a frame whose last strip is partial; against one-device frames and the oracle."""
+    import torch
+
+    one = c2.Context(0)
+    multi = c2.Context(devices=[0, 0, 0])
+    assert multi.deviceCount == 3 and one.deviceCount == 1
+    try:
+        for name, kw in [("lecture5_333x217_t4", {}), ("lecture5_640x480_t5", {}), ("csg_stress_320x240_t1", {}),
+                         ("zaphod_215x143_dof25", {}), ("lecture4_640x480_t1", {"prepass_bucket": 48})]:
+            scene, cam, opts = load_config(name, count_rays=1, **kw)
+            one.uploadScene(scene.desc)
+            multi.uploadScene(scene.desc)
+            a = one.renderFrame(cam, opts)
+            ra = one.rayStats()
+            b = multi.renderFrame(cam, opts)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+            assert multi.rayStats() == ra, name
+            dev = torch.full((opts.height, opts.width, 3), -1.0, dtype=torch.float32, device="cuda:0")
+            multi.renderFrameDevice(cam, opts, dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(dev.cpu().numpy().view(np.uint32), a.view(np.uint32)), name
+            assert multi.rayStats() == ra, name
+            assert np.array_equal(multi.renderFrameRGB32(cam, opts), one.renderFrameRGB32(cam, opts)), name
+            ref = orc.render_frame(scene.desc, cam, opts, 0)
+            md, nbad, nne = maxdiff(b, ref)
+            assert md <= TOL, (name, md)
+    finally:
+        multi.close()
+        one.close()
+
+
+def test_two_scenes_alternating_on_one_context(gpu_ctx):
+    """A context holds ONE scene.  Two Renderers (host scene objects) sharing a Context must each get
+    their own scene rendered whenever it is their turn — also after a direct uploadScene of something
+    else — never the other scene's tables under this scene's camera."""
+    sa = c2.parseSceneFromFile(os.path.join(SCENES, "lecture4.sdl"))
+    sb = c2.parseSceneFromFile(os.path.join(SCENES, "lecture5.sdl"))
+    for s in (sa, sb):
+        s.setFrameSize(160, 120)
+    ra, rb = c2.Renderer(sa, gpu_ctx), c2.Renderer(sb, gpu_ctx)
+    refs = {}
+    for key, s in (("a", sa), ("b", sb)):
+        refs[key] = orc.render_frame(s.desc, s.beginFrame(), s.renderOpts(), 0)
+    gens = set()
+    for turn in ("a", "b", "a", "a", "b", "upload", "a", "b"):
+        if turn == "upload":
+            other = c2.parseSceneFromFile(os.path.join(SCENES, "zaphod.sdl"))
+            gpu_ctx.uploadScene(other.desc)
+            continue
+        img = (ra if turn == "a" else rb).renderRT()
+        gens.add(gpu_ctx.sceneGeneration)
+        md, nbad, nne = maxdiff(img, refs[turn])
+        assert md <= TOL, (turn, md)
+        s = sa if turn == "a" else sb
+        probe = (ra if turn == "a" else rb).renderPixelNoAA(80, 100)   # one sample, no AA (rt/renderer.d:46-57)
+        want = orc.render_pixel(s.desc, s.beginFrame(), s.renderOpts(), 80, 100)
+        assert probe.closest_node == want.closest_node and np.allclose(np.array(probe.color), np.array(want.color), atol=TOL), turn
+    assert len(gens) >= 5      # every switch of scene was a fresh upload with a new generation
+
+
 def test_planes_only_scenes(gpu_ctx, tmp_path, scenes_dir):
     """Scenes made of Plane nodes only run the kernel instances that decide a plane's miss from the
     un-normalised ray (plane_points_away): scaled / mirrored / translated / bounded planes, lights
