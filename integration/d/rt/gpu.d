@@ -71,6 +71,9 @@ extern (C) nothrow @nogc
     }
 
     int c2rt_init(int device, c2rt_ctx** outCtx);
+    int c2rt_init_multi(int device_count_or_0, const(int)* device_ids, c2rt_ctx** outCtx);
+    int c2rt_device_count(const c2rt_ctx*);
+    ulong c2rt_scene_generation(const c2rt_ctx*);
     void c2rt_destroy(c2rt_ctx*);
     const(char)* c2rt_last_error(const c2rt_ctx*);
     int c2rt_upload_scene(c2rt_ctx*, const c2rt_scene_desc*);
@@ -198,9 +201,21 @@ final class GpuRenderer
 {
     private c2rt_ctx* ctx;
     private GpuScene uploaded;
+    private float* pinned;   // the screen buffer currently page-locked through this context
 
-    this(int device = -1) { enforce(c2rt_init(device, &ctx) == C2RT_OK, "no usable GPU"); }
-    ~this() { if (ctx) c2rt_destroy(ctx); }
+    /// device >= 0: that GPU; device < 0: the current one; allDevices: ONE context over every visible
+    /// GPU (c2rt_init_multi(0, null)): frames are dealt to the GPUs in interleaved 8-row strips and every
+    /// GPU copies its strips straight into `output.pixels` over its own PCIe link.
+    this(int device = -1, bool allDevices = false)
+    {
+        auto st = allDevices ? c2rt_init_multi(0, null, &ctx) : c2rt_init(device, &ctx);
+        enforce(st == C2RT_OK, "no usable GPU");
+    }
+    ~this()
+    {
+        if (ctx && pinned) c2rt_unpin_host_buffer(ctx, pinned);
+        if (ctx) c2rt_destroy(ctx);
+    }
 
     void upload(const Scene scene)
     {
@@ -209,7 +224,16 @@ final class GpuRenderer
     }
 
     /// `screen.alloc` happened (gui/raytracer_demo.d:181-182): let frames stream back at PCIe rate.
-    void pin(Image!Color screen) { c2rt_pin_host_buffer(ctx, cast(float*) screen.pixels.ptr, screen.pixels.length * Color.sizeof); }
+    /// The GUI re-allocates `screen` on every resize (gui/raytracer_demo.d:135-143,181-182): the previous
+    /// buffer is unpinned first (its pages may already be back with the GC), then the new one is registered.
+    void pin(Image!Color screen)
+    {
+        auto p = cast(float*) screen.pixels.ptr;
+        if (pinned && pinned !is p) { c2rt_unpin_host_buffer(ctx, pinned); pinned = null; }
+        if (c2rt_pin_host_buffer(ctx, p, screen.pixels.length * Color.sizeof) == C2RT_OK) pinned = p;
+    }
+    /// Call before the GUI frees or re-allocates the buffer passed to pin().
+    void unpin() { if (pinned) { c2rt_unpin_host_buffer(ctx, pinned); pinned = null; } }
 
     /// Drop-in for `Renderer(scene, output, isRendering, isStopRequested).renderRT()`; call after scene.beginFrame().
     int renderRT(const Scene scene, Image!Color output, shared(bool)* isRendering, const shared(bool)* isStopRequested)
