@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -67,6 +68,8 @@ struct c2rt_ctx {
     unsigned long long *counters = nullptr; /* [2] */
     c2rt_trace_result *probe = nullptr;
     uint8_t *srgb_lut = nullptr;   /* [4097] */
+    uint32_t *retry_list = nullptr; /* RenderParams::retry_list: [0] count, then tile (block) indices */
+    size_t retry_words = 0;
     bool counters_valid = false;
     hipStream_t counters_stream = nullptr;
 };
@@ -432,6 +435,43 @@ KernelVariant variant_of(const c2rt_ctx *ctx, const c2rt_camera_frame *cam)
     return v;
 }
 
+/* One frame launch.  Scenes with nested CsgOps (depth >= 2) run the kernel with a reduced hit-stack
+ * capacity (two waves per SIMD instead of one at depth 4) and then, on the same stream, the
+ * full-capacity relaunch over the tiles that overflowed it — none, for trees whose primitives yield
+ * their two hits (RenderParams::retry_list; c2rt_kernels.hip, csg_intersect).  Returns a hipError_t. */
+int launch_frame(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStream_t stream)
+{
+    const int levels = ctx->csg_levels;
+    /* test hook: C2RT_CSG_FIRST_CAP=<entries> shrinks the first pass's stack so that the overflow ->
+     * retry path runs on ordinary scenes (tests/test_gpu_parity.py); never below 1, never above full */
+    static const int forced_cap = [] { const char *e = std::getenv("C2RT_CSG_FIRST_CAP"); return e ? std::atoi(e) : 0; }();
+    int first_cap = kCsgFirstCap(levels);
+    if (forced_cap > 0 && levels >= 2) first_cap = forced_cap < kCsgFullCap(levels) ? forced_cap : kCsgFullCap(levels);
+    p.csg_cap = (uint32_t)first_cap;
+    if (levels == 0) p.csg_cap = 0;
+    p.retry_mode = 0;
+    if (levels < 2) return launch_render(p, v, stream);
+    const size_t blocks = (size_t)p.blocks_x * ((p.tiles_y + 7u) / 8u * 8u);
+    if (blocks + 1 > ctx->retry_words) {
+        if (ctx->retry_list) { (void)hipFree(ctx->retry_list); ctx->retry_list = nullptr; ctx->retry_words = 0; }
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->retry_list), (blocks + 1) * sizeof(uint32_t));
+        if (e != hipSuccess) return (int)e;
+        ctx->retry_words = blocks + 1;
+    }
+    p.retry_list = ctx->retry_list;
+    p.retry_max = (uint32_t)blocks;
+    hipError_t e = hipMemsetAsync(ctx->retry_list, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    int r = launch_render(p, v, stream);
+    if (r != 0 || first_cap >= kCsgFullCap(levels)) return r;
+    p.retry_mode = 1;
+    p.csg_cap = (uint32_t)kCsgFullCap(levels);
+    r = launch_render(p, v, stream);
+    p.retry_mode = 0;
+    p.csg_cap = (uint32_t)first_cap;
+    return r;
+}
+
 int render_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_dev,
                   hipStream_t stream)
 {
@@ -444,7 +484,7 @@ int render_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render
         p.ray_counters = ctx->counters;
     }
     if (p.local_rows == 0) return C2RT_OK;
-    const int e = launch_render(p, variant_of(ctx, cam), stream);
+    const int e = launch_frame(ctx, p, variant_of(ctx, cam), stream);
     if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
     if (opts->count_rays) {
         ctx->counters_valid = true;
@@ -560,7 +600,7 @@ void c2rt_destroy(c2rt_ctx *ctx)
         if (e) (void)hipEventDestroy(e);
     for (const auto &pb : ctx->pinned) (void)hipHostUnregister(pb.first);
     void *bufs[] = {ctx->geoms, ctx->nodes, ctx->shaders, ctx->textures, ctx->lights, ctx->texels,
-                    ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut, ctx->shadow_rects};
+                    ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut, ctx->shadow_rects, ctx->retry_list};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete ctx;
@@ -921,7 +961,7 @@ static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2r
         p.local_rows = rows - off < chunk ? rows - off : chunk;
         p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
         if (chunk < rows) p.row_group_start = 0; /* the rotation is relative to the whole frame's rows */
-        int e = launch_render(p, variant, ctx->stream);
+        int e = launch_frame(ctx, p, variant, ctx->stream);
         if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
         const void *src = ctx->frame + off * row_floats;
         if (out_rgb32) {
@@ -995,7 +1035,7 @@ static int render_to_host_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, con
             if (hipMemsetAsync(c->counters, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) { st = fail(ctx, C2RT_ERR_HIP, "counter reset"); break; }
             p.ray_counters = c->counters;
         }
-        int e = launch_render(p, variant, c->stream);
+        int e = launch_frame(c, p, variant, c->stream);
         if (e != 0) { st = fail(ctx, C2RT_ERR_HIP, "render kernel launch (slot %u): %s", d, hipGetErrorString((hipError_t)e)); break; }
         const char *src = reinterpret_cast<const char *>(c->frame);
         if (out_rgb32) {
@@ -1066,7 +1106,7 @@ static int render_device_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, cons
             p.ray_counters = c->counters;
         }
         if (p.local_rows) {
-            const int e = launch_render(p, variant, s);
+            const int e = launch_frame(c, p, variant, s);
             if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch (slot %u): %s", d, hipGetErrorString((hipError_t)e));
         }
         if (d != 0) HIP_TRY(ctx, hipEventRecord(c->ev_done, s));
@@ -1188,6 +1228,7 @@ int c2rt_render_pixel(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
     fill_params(ctx, cam, opts, p);
     p.n_cull = 0; /* the probe launch has no tile: never cull */
     p.n_cull_lights = 0;
+    p.csg_cap = (uint32_t)kCsgFullCap(C2RT_MAX_CSG_DEPTH); /* the probe instance handles every depth */
     p.probe_x = x;
     p.probe_y = y;
     p.probe_out = ctx->probe;

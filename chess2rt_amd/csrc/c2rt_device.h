@@ -34,8 +34,14 @@ constexpr int kMaxCullLights = C2RT_MAX_CULL_LIGHTS; /* lights beyond this get n
 #endif
 constexpr int kWavesPerBlock = C2RT_WAVES_PER_BLOCK; /* horizontally adjacent tiles per workgroup */
 constexpr int kBlockThreads = kWave * kWavesPerBlock;
-/* LDS bytes one wavefront needs per CSG nesting level: dist[16][64] (8 B) + tag[16][64] (2 B) = 10 KiB */
-constexpr int kCsgLdsPerLevel = kCsgEntries * kWave * (8 + 2);
+/* LDS bytes per entry of a wavefront's CSG hit stack: dist[64] (8 B) + tag[64] (2 B) */
+constexpr int kCsgLdsPerEntry = kWave * (8 + 2);
+/* a CsgOp's list holds at most 8 + 8 entries and lists nest: depth x 16 entries can never overflow */
+constexpr int kCsgFullCap(int levels) { return kCsgEntries * (levels > 0 ? levels : 1); }
+/* first-pass capacity per nesting depth (10 / 10 / 15 / 20 KiB per wave): what non-pathological trees
+ * need with margin (two hits per primitive child = 4 entries per level); tiles that overflow are
+ * rendered again at kCsgFullCap */
+constexpr int kCsgFirstCap(int levels) { return levels <= 1 ? 16 : (levels == 2 ? 16 : (levels == 3 ? 24 : 32)); }
 
 enum GeomFlags : int32_t {
     kGeomBounded = 1,              /* `bound` is valid: a ray that misses it cannot hit */
@@ -180,6 +186,12 @@ struct RenderParams {
     uint32_t blocks_x;             /* ceil(tiles_x / kWavesPerBlock) */
     uint32_t row_group_start;      /* first group of 8 tile rows to dispatch (< ceil(tiles_y / 8)) */
     uint64_t seed;
+    /* CSG hit stack (c2rt_kernels.hip, csg_intersect): entries per wave of this launch, and the list
+     * of tiles whose stacks overflowed — [0] = count, then block indices; retry_mode = 1: this launch
+     * renders the listed tiles (at full capacity) instead of the whole grid */
+    uint32_t csg_cap;
+    uint32_t retry_mode, retry_max;
+    uint32_t *retry_list;
     float *out;                    /* local_rows * width * 3 floats */
     unsigned long long *ray_counters; /* [2] primary, shadow (nullable) */
     /* pixel probe */

@@ -48,10 +48,13 @@ __device__ __noinline__ double c2_cos(double a) { return cos(a); }
 #elif defined(C2RT_UNIT) && C2RT_UNIT == 2
 #define C2RT_OCC __attribute__((amdgpu_waves_per_eu(2, 2))) /* 198 VGPRs, no scratch */
 #elif defined(C2RT_UNIT) && C2RT_UNIT >= 3
-/* every nesting level keeps its stepping state live (all levels are inlined
- * once): ~255 VGPRs without scratch; the LDS slabs (10 KiB per level and wave)
- * cap residency below one wave per SIMD anyway */
-#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(1, 1)))
+/* every nesting level keeps its stepping state live (all levels are inlined once): 215 (depth 3) /
+ * 253 (depth 4) VGPRs without scratch — just inside the 256 that still allow two waves per SIMD, which
+ * the shared hit stack (20 KiB per wave at depth 4 instead of 40 KiB of per-level slabs) now lets a CU hold */
+#ifndef C2RT_OCC_DEEP
+#define C2RT_OCC_DEEP 2
+#endif
+#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(C2RT_OCC_DEEP, C2RT_OCC_DEEP)))
 #else
 /* depth-1 CSG kernel: with 10 KiB slabs 16 waves fit a CU's LDS, and 4 waves/SIMD with 39 spilled VGPRs
  * (80 B of scratch per lane) are 2 % faster on multi-tap frames (lecture5 4K x5: 1.525 -> 1.490 ms) and 3 %
@@ -162,8 +165,14 @@ struct Ctx {
     const DevGeom *geoms;
     const DevNode *nodes;
     uint32_t n_nodes;
-    char *lds;        /* this wave's CSG slabs */
+    char *lds;        /* this wave's CSG hit stack: dist[csg_cap][64] (8 B) then tag[csg_cap][64] (2 B) */
     int lane;
+    int csg_cap;      /* entries of that stack (wave-uniform, RenderParams::csg_cap) */
+    /* A lane's nested hit lists did not fit csg_cap entries: its results are void and the whole tile is
+     * rendered again by the full-capacity launch (RenderParams::retry_list).  Written through const
+     * references on purpose: everything here is inlined into the kernel and it lives in a register. */
+    mutable bool overflow;
+    uint32_t block;   /* the tile this wave renders (blockIdx.x, or an entry of the retry list) */
     uint32_t primary_mask; /* bit n clear: no primary ray of this tile can reach node n (wave-uniform) */
     uint32_t shadow_mask0; /* same for the tile's shadow rays towards light 0 (further lights: shadow_cull_mask) */
     /* the ground plane (RenderParams::ground_node) is the ONLY node left in shadow_mask0: the tile's
@@ -345,7 +354,7 @@ DEV bool geom_is_inside(const Ctx &cx, int gid, D3 p)
 /* ------------------------------------------------------------------ */
 
 template <int LEVEL, int NEED>
-__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h, bool full);
+__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h, bool full, int base);
 
 /* hit-list tag: leaf geometry (12 bits: C2RT_MAX_CSG_GEOMS) | child side | index of the hit in its child's list */
 static_assert(kMaxCsgHits <= 8 && C2RT_MAX_CSG_GEOMS <= 4096, "16-bit hit tags");
@@ -367,12 +376,21 @@ DEV uint16_t csg_tag(int leaf, int side, int k) { return (uint16_t)(((uint32_t)l
  * child's geometry record stays a scalar load.  Whether the replayed hit needs
  * its normal / u,v is a per-lane flag (`full`), because lanes replay at
  * different steps. */
+/* LDS: one hit STACK per wave instead of a fixed 16-entry slab per nesting level.  The list of a
+ * CsgOp starts at the per-lane index `base`; while a child is being stepped the child's own lists
+ * live above the parent's current top (base + n + k) and are dead when the child returns, so the
+ * parent's next entry overwrites them.  Typical trees need 4 entries per level (two hits per
+ * primitive child) where the slabs reserved 16: a depth-4 scene runs in 20 KiB per wave instead of
+ * 40, i.e. two waves per SIMD instead of one.  A lane that would push beyond csg_cap raises
+ * Ctx::overflow and stops collecting; its tile is redone by the full-capacity launch
+ * (16 entries x depth, which cannot overflow: every level holds at most 8 + 8). */
 template <int LEVEL, int NEED>
-__device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, const ORay &ray, Hit &h, bool full)
+__device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, const ORay &ray, Hit &h, bool full, int base)
 {
-    static_assert(LEVEL >= 1, "CSG needs a slab");
-    double *ldist = reinterpret_cast<double *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel) + cx.lane;
-    uint16_t *ltag = reinterpret_cast<uint16_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
+    static_assert(LEVEL >= 1, "CSG needs a stack");
+    double *ldist = reinterpret_cast<double *>(cx.lds) + cx.lane + base * kWave;
+    uint16_t *ltag = reinterpret_cast<uint16_t *>(cx.lds + cx.csg_cap * (kWave * 8)) + cx.lane + base * kWave;
+    const int room = cx.csg_cap - base; /* entries this list may use */
     const int type = G->type, left = G->left, right = G->right, flags = G->flags;
     const D3 d = ray.d;
     const bool want_full = NEED == kFull || (NEED == kRt && full);
@@ -394,11 +412,13 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
         int k = 0;
         while (k < limit) {
             t.dist = 1e99;
-            if (!geom_intersect<LEVEL - 1, kRt>(cx, child, rr, t, replay && k == wk && want_full)) break;
+            /* the child's lists go above this list's top; a replay no longer needs this list */
+            if (!geom_intersect<LEVEL - 1, kRt>(cx, child, rr, t, replay && k == wk && want_full, replay ? base : base + n + k)) break;
             t.dist += cur;
             cur = t.dist;
             rr.o = t.p + d * 1e-6;
             if (!replay) {
+                if (n + k >= room) { cx.overflow = true; break; }
                 ldist[(n + k) * kWave] = t.dist;
                 ltag[(n + k) * kWave] = csg_tag(t.g, side, k);
             }
@@ -459,11 +479,12 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
  * compile-time NEED for the collect loops — measurably faster than the single
  * call-site form, and the duplicated primitive code is small. */
 template <int NEED>
-__device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom *G, const ORay &ray, Hit &h, bool full)
+__device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom *G, const ORay &ray, Hit &h, bool full, int base)
 {
     constexpr int LEVEL = 1;
-    double *ldist = reinterpret_cast<double *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel) + cx.lane;
-    uint16_t *ltag = reinterpret_cast<uint16_t *>(cx.lds + (LEVEL - 1) * kCsgLdsPerLevel + kCsgEntries * kWave * 8) + cx.lane;
+    double *ldist = reinterpret_cast<double *>(cx.lds) + cx.lane + base * kWave;
+    uint16_t *ltag = reinterpret_cast<uint16_t *>(cx.lds + cx.csg_cap * (kWave * 8)) + cx.lane + base * kWave;
+    const int room = cx.csg_cap - base;
     const int type = G->type, left = G->left, right = G->right, flags = G->flags;
     const D3 d = ray.d;
 
@@ -478,10 +499,11 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
         while (k < kMaxCsgHits) {
             Hit t;
             t.dist = 1e99;
-            if (!geom_intersect<0, kPoint>(cx, child, rr, t, false)) break;
+            if (!geom_intersect<0, kPoint>(cx, child, rr, t, false, 0)) break;
             t.dist += cur;
             cur = t.dist;
             rr.o = t.p + d * 1e-6;
+            if (n + k >= room) { cx.overflow = true; break; }
             ldist[(n + k) * kWave] = t.dist;
             ltag[(n + k) * kWave] = csg_tag(t.g, side, k);
             ++k;
@@ -533,14 +555,14 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
     for (int i = 0; i < wk; ++i) {
         Hit t;
         t.dist = 1e99;
-        geom_intersect<0, kPoint>(cx, child, rr, t, false);
+        geom_intersect<0, kPoint>(cx, child, rr, t, false, 0);
         t.dist += cur;
         cur = t.dist;
         rr.o = t.p + d * 1e-6;
     }
     Hit t;
     t.dist = 1e99;
-    geom_intersect<0, NEED>(cx, child, rr, t, full);
+    geom_intersect<0, NEED>(cx, child, rr, t, full, 0);
     t.dist += cur;
     h = t;
 
@@ -553,25 +575,26 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
 
 /* Geometry.intersect on a given record: `G` is wave-uniform, so this is a scalar branch. */
 template <int LEVEL, int NEED>
-__device__ __forceinline__ bool geom_intersect_rec(const Ctx &cx, const DevGeom *G, int gid, const ORay &r, Hit &h, bool full)
+__device__ __forceinline__ bool geom_intersect_rec(const Ctx &cx, const DevGeom *G, int gid, const ORay &r, Hit &h, bool full, int base)
 {
     const int type = G->type;
     if (type == C2RT_GEOM_PLANE) return plane_intersect<NEED>(G, gid, r, h, full);
     if (type == C2RT_GEOM_SPHERE) return sphere_intersect<NEED>(G, gid, r, h, full);
     if (type == C2RT_GEOM_CUBE) return cube_intersect<NEED>(G, gid, r, h, full);
     if constexpr (LEVEL >= 2) {
-        return csg_intersect<LEVEL, NEED>(cx, G, r, h, full);
+        return csg_intersect<LEVEL, NEED>(cx, G, r, h, full, base);
     } else if constexpr (LEVEL == 1) {
-        return csg_intersect_leaf<NEED>(cx, G, r, h, full);
+        return csg_intersect_leaf<NEED>(cx, G, r, h, full, base);
     } else {
         return false;
     }
 }
 
+/* `base`: first free entry of this lane's hit stack (CsgOps only) */
 template <int LEVEL, int NEED>
-__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h, bool full)
+__device__ __forceinline__ bool geom_intersect(const Ctx &cx, int gid, const ORay &r, Hit &h, bool full, int base)
 {
-    return geom_intersect_rec<LEVEL, NEED>(cx, cx.geoms + gid, gid, r, h, full);
+    return geom_intersect_rec<LEVEL, NEED>(cx, cx.geoms + gid, gid, r, h, full, base);
 }
 
 /* ------------------------------------------------------------------ */
@@ -673,7 +696,7 @@ DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &b
     if (G->type >= C2RT_GEOM_CUBE && (G->flags & kGeomBounded) && misses_bound(G, rc)) return false;
     Hit h;
     h.dist = best.dist * len;
-    if (!geom_intersect_rec<LEVELS, NEED>(cx, G, gid, rc, h, false)) return false;
+    if (!geom_intersect_rec<LEVELS, NEED>(cx, G, gid, rc, h, false, 0)) return false;
     if (NEED == kBool) return true;
     best.dist = h.dist / len;
     best.g = h.g;
@@ -699,9 +722,8 @@ DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &b
 
 /* Frame-space pixel bounds of this wave's tile: x in [tx0, tx0 + 8), rows
  * ty0..ty1 (the strip map is monotonic in the local row). */
-DEV void tile_bounds(const RenderParams &P, int &tx0, int &ty0, int &ty1)
+DEV void tile_bounds(const RenderParams &P, uint32_t b, int &tx0, int &ty0, int &ty1)
 {
-    const uint32_t b = blockIdx.x;
 #if C2RT_XCD_SWIZZLE
     const uint32_t xcd = b & 7u, j = b >> 3;
     /* row groups are walked starting at P.row_group_start (where the boxed nodes begin on screen):
@@ -747,11 +769,11 @@ DEV void lane_rect(const RenderParams &P, int lane, bool &mine, int &r0, int &r1
  * plane of the pyramid while the light is on the inner side of that plane is in a
  * half space none of those segments enters.  Lanes that are not active (missed,
  * left the frame) cannot vote: their nodes stay "may occlude". */
-DEV uint32_t shadow_cull_mask(const RenderParams &P, int lane, uint32_t l)
+DEV uint32_t shadow_cull_mask(const RenderParams &P, uint32_t block, int lane, uint32_t l)
 {
     if (!P.n_cull || l >= P.n_cull_lights) return 0xFFFFFFFFu;
     int tx0, ty0, ty1;
-    tile_bounds(P, tx0, ty0, ty1);
+    tile_bounds(P, block, tx0, ty0, ty1);
     /* sample coordinates of this tile: x in [tx0, tx0 + 8.6), y in [ty0, ty1 + 0.6] */
     const int sx1 = tx0 + kTileW + 1, sy1 = ty1 + 1;
     bool mine;
@@ -907,7 +929,7 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const 
         if (L->lit) {
             const D3 lightPos = ld3(L->pos);
             shadow_rays += 1;
-            if (test_visibility<LEVELS, PO>(cx, h.p + N * 1e-6, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.lane, l) : 0xFFFFFFFFu), l == 0 && cx.shadow_ground_only)) {
+            if (test_visibility<LEVELS, PO>(cx, h.p + N * 1e-6, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.block, cx.lane, l) : 0xFFFFFFFFu), l == 0 && cx.shadow_ground_only)) {
                 const F3 lightColor = ldf3(L->color);
                 const D3 lightDir = normalized(lightPos - h.p);
                 const double cosTheta = dot(lightDir, N);
@@ -1154,18 +1176,17 @@ __constant__ double k_aa_y[5] = {0.0, 0.3, 0.0, 0.6, 0.6};
  * pixel).  One workgroup = one wavefront = one 8x8 tile.
  */
 template <int LEVELS, bool DOF, bool MLC, bool PO>
-DEV void render_body(const RenderParams &P)
+DEV void render_tile(const RenderParams &P, const uint32_t b)
 {
     extern __shared__ __align__(16) char lds_all[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    char *lds = lds_all + (size_t)wave * LEVELS * kCsgLdsPerLevel;
+    char *lds = lds_all + (size_t)wave * P.csg_cap * kCsgLdsPerEntry;
 
     /* XCD-aware block -> tile: blocks b and b+8 share an XCD (round-robin
      * dispatch), so XCD x gets tile rows x, x+8, x+16, ... and walks them
      * left to right.  A block is kWavesPerBlock horizontally adjacent 8x8
      * tiles, one per wavefront. */
-    const uint32_t b = blockIdx.x;
 #if C2RT_XCD_SWIZZLE
     const uint32_t xcd = b & 7u, j = b >> 3;
     /* row groups are walked starting at P.row_group_start (where the boxed nodes begin on screen):
@@ -1189,12 +1210,12 @@ DEV void render_body(const RenderParams &P)
     if constexpr (!DOF) {
         if (P.n_cull) {
             int tx0, ty0, ty1;
-            tile_bounds(P, tx0, ty0, ty1);
+            tile_bounds(P, b, tx0, ty0, ty1);
             bool mine;
             int r0, r1, r2, r3;
             lane_rect(P, lane, mine, r0, r1, r2, r3);
             pmask = (uint32_t)__ballot(!mine || !(r2 <= tx0 || r0 >= tx0 + kTileW || r3 <= ty0 || r1 > ty1));
-            smask0 = shadow_cull_mask(P, lane, 0);
+            smask0 = shadow_cull_mask(P, b, lane, 0);
             /* Ground-plane refinement (RenderParams::ground_node): if this tile's primary rays can only
              * reach the ground plane, all its hit points lie inside the tile's footprint on that plane
              * — the convex image of the pixel rectangle (+1 px all round; the AA taps reach 0.6 px),
@@ -1245,6 +1266,9 @@ DEV void render_body(const RenderParams &P)
     cx.n_nodes = P.n_nodes;
     cx.lds = lds;
     cx.lane = lane;
+    cx.csg_cap = (int)P.csg_cap;
+    cx.overflow = false;
+    cx.block = b;
     cx.primary_mask = pmask;
     cx.shadow_mask0 = smask0;
     cx.shadow_ground_only = ground_only;
@@ -1278,6 +1302,18 @@ DEV void render_body(const RenderParams &P)
     }
     if (ntaps > 1) accum = accum / (float)ntaps; /* `accum / 5`: Color / float */
 
+    if constexpr (LEVELS >= 2) {
+        /* some lane's nested hit lists outgrew the stack: nothing of this tile is kept; the
+         * full-capacity launch that follows renders the tiles on this list */
+        if (__ballot(cx.overflow)) {
+            if (lane == (int)__builtin_ctzll(__ballot(true))) {
+                const uint32_t slot = atomicAdd(P.retry_list, 1u);
+                if (slot < P.retry_max) P.retry_list[1 + slot] = b;
+            }
+            return;
+        }
+    }
+
     float *px = P.out + ((size_t)(P.frame_rows ? y : lr) * P.width + x) * 3;
     px[0] = accum.r;
     px[1] = accum.g;
@@ -1286,6 +1322,29 @@ DEV void render_body(const RenderParams &P)
     if (P.ray_counters) {
         atomicAdd(P.ray_counters + 0, (unsigned long long)cnt.primary);
         atomicAdd(P.ray_counters + 1, (unsigned long long)cnt.shadow);
+    }
+}
+
+/* One tile per workgroup; in retry mode (RenderParams::retry_mode: the full-capacity relaunch of
+ * the nested-CSG instances) a fixed grid walks the list of tiles whose hit stacks overflowed.
+ * Either way the tile code is inlined once. */
+template <int LEVELS, bool DOF, bool MLC, bool PO>
+DEV void render_body(const RenderParams &P)
+{
+    if constexpr (LEVELS >= 2) {
+        uint32_t i = blockIdx.x;
+        do {
+            uint32_t b = i;
+            if (P.retry_mode) {
+                const uint32_t listed = P.retry_list[0];
+                if (i >= (listed < P.retry_max ? listed : P.retry_max)) break;
+                b = P.retry_list[1 + i];
+            }
+            render_tile<LEVELS, DOF, MLC, PO>(P, b);
+            i += gridDim.x;
+        } while (P.retry_mode);
+    } else {
+        render_tile<LEVELS, DOF, MLC, PO>(P, blockIdx.x);
     }
 }
 
@@ -1323,6 +1382,9 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.n_nodes = P.n_nodes;
     cx.lds = lds;
     cx.lane = 0;
+    cx.csg_cap = (int)P.csg_cap;
+    cx.overflow = false;
+    cx.block = 0;
     cx.primary_mask = 0xFFFFFFFFu;
     cx.shadow_mask0 = 0xFFFFFFFFu;
     cx.shadow_ground_only = false;
@@ -1396,8 +1458,9 @@ int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, vo
 #else
     const uint32_t tiles_y_pad = p.tiles_y;
 #endif
-    const dim3 grid(p.blocks_x * tiles_y_pad), block(kBlockThreads);
-    const size_t lds = (size_t)C2RT_UNIT * kCsgLdsPerLevel * kWavesPerBlock;
+    /* retry mode: a fixed grid walks the overflow list (render_body) */
+    const dim3 grid(p.retry_mode ? 2048u : p.blocks_x * tiles_y_pad), block(kBlockThreads);
+    const size_t lds = (size_t)p.csg_cap * kCsgLdsPerEntry * kWavesPerBlock;
 #if C2RT_UNIT == 0
     if (p.planes_only) {
         if (dof_or_stereo)
@@ -1433,7 +1496,7 @@ int launch_render(const RenderParams &p, const KernelVariant &v, void *stream)
 /* the probe is not a hot path: one instance that handles every scene */
 int launch_probe(const RenderParams &p, const KernelVariant &, void *stream)
 {
-    const size_t lds = (size_t)C2RT_MAX_CSG_DEPTH * kCsgLdsPerLevel;
+    const size_t lds = (size_t)p.csg_cap * kCsgLdsPerEntry;
     hipLaunchKernelGGL((probe_kernel<C2RT_MAX_CSG_DEPTH, true>), dim3(1), dim3(kWave), lds,
                        static_cast<hipStream_t>(stream), p);
     return (int)hipGetLastError();

@@ -646,6 +646,43 @@ def test_two_scenes_alternating_on_one_context(gpu_ctx):
     assert len(gens) >= 5      # every switch of scene was a fresh upload with a new generation
 
 
+@pytest.mark.parametrize("cap", [1, 3, 6, 11])
+def test_csg_hit_stack_overflow_is_redone_at_full_capacity(cap):
+    """Nested-CSG scenes run with a reduced LDS hit stack first; tiles in which a lane's nested lists
+    outgrow it are rendered again by the full-capacity launch.  C2RT_CSG_FIRST_CAP (a test hook read
+    at library load) forces tiny stacks, so that most CSG tiles of ordinary scenes take that path: the
+    frames, the ray counts and a strip-sharded render must not change."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import chess2rt_amd as c2, oracle_lib as orc
+from golden_configs import load_config
+ctx = c2.Context(0)
+for name in ("csg_stress_320x240_t5", "csg_corner_256x192_t1"):
+    scene, cam, opts = load_config(name, count_rays=1)
+    ctx.uploadScene(scene.desc)
+    a = ctx.renderFrame(cam, opts)
+    rays = ctx.rayStats()
+    st = {}
+    ref = orc.render_frame(scene.desc, cam, opts, 0, st)
+    assert np.array_equal(a.view(np.uint32), ref.view(np.uint32)), name
+    assert rays == (st["primary"], st["shadow"]), name
+    _, _, o2 = load_config(name, strip_height=8, strip_rank=1, strip_world=3)
+    b = ctx.renderFrame(cam, o2)
+    rows = [y for y in range(opts.height) if (y // 8) % 3 == 1]
+    assert np.array_equal(b.view(np.uint32), ref[rows].view(np.uint32)), name
+print("ok")
+'''
+    env = dict(os.environ, C2RT_CSG_FIRST_CAP=str(cap))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout + p.stderr
+
+
 def test_planes_only_scenes(gpu_ctx, tmp_path, scenes_dir):
     """Scenes made of Plane nodes only run the kernel instances that decide a plane's miss from the
     un-normalised ray (plane_points_away): scaled / mirrored / translated / bounded planes, lights
