@@ -9,6 +9,11 @@ ARCH       ?= gfx950
 FPFLAGS    := -ffp-contract=off -fno-fast-math
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt \
               -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical $(EXTRA_HIPFLAGS)
+# Kernel units only.  Machine LICM hoists loop-invariant scalar and vector values out of the node / CSG
+# stepping loops of a kernel that is already at its register budget: more values live across the loops,
+# more SGPRs spilled to VGPR lanes.  Measured with it off (profiles/r02_variants.md): lecture5 4K 1 tap
+# 0.389 -> 0.375 ms, zaphod DOF 5.23 -> 5.04 ms, depth-4 VGPR spills 90 -> 60.
+KERNELFLAGS := -mllvm -disable-machine-licm
 CXXFLAGS   := -O2 -std=c++17 -fPIC $(FPFLAGS) -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 CSRC       := chess2rt_amd/csrc
 # development knob: `make VARIANT=name EXTRA_HIPFLAGS=... EXTRA_KERNEL_FLAGS=...` builds chess2rt_amd/libc2rt_name.so
@@ -27,7 +32,7 @@ $(BUILD):
 	mkdir -p $(BUILD)
 
 $(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
-	$(HIPCC) $(HIPFLAGS) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$* -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$* -c $< -o $@
 
 $(BUILD)/c2rt_api.o: $(CSRC)/c2rt_api.cpp $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
 	g++ $(CXXFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@

@@ -657,6 +657,15 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         d.left = is_csg(t) ? s->geom_child[2 * g + 0] : -1;
         d.right = is_csg(t) ? s->geom_child[2 * g + 1] : -1;
         for (int i = 0; i < 4; ++i) d.p[i] = s->geom_param[4 * g + i];
+        if (t == C2RT_GEOM_CUBE) {
+            const double halfSide = d.p[3] * 0.5;
+            for (int i = 0; i < 3; ++i) {
+                d.q[i] = d.p[i] + -1 * halfSide;     /* center + side * halfSide, side = -1 (== center - halfSide) */
+                d.q[3 + i] = d.p[i] + 1 * halfSide;
+            }
+        } else if (t == C2RT_GEOM_SPHERE) {
+            d.q[0] = d.p[3] * d.p[3];
+        }
     }
     std::vector<int> state(s->n_geoms, 0), memo(s->n_geoms, 0);
     std::vector<BoundInfo> bounds(s->n_geoms);

@@ -55,7 +55,7 @@ enum GeomFlags : int32_t {
     kCsgShortB = 4,
 };
 
-struct alignas(16) DevGeom {       /* 80 B */
+struct alignas(16) DevGeom {       /* 128 B */
     int32_t type, left, right;
     int32_t flags;                 /* GeomFlags */
     double p[4];                   /* plane: y, limit | sphere: c, R | cube: c, side */
@@ -65,6 +65,12 @@ struct alignas(16) DevGeom {       /* 80 B */
      * (c2rt_api.cpp: cube = half diagonal, Union = both children, Inter/Diff =
      * left child, Plane = unbounded). */
     double bound[4];
+    /* Wave-uniform subexpressions of the intersection tests, evaluated once at upload with the same
+     * IEEE operations the reference evaluates per ray (so the bits are the same) instead of per lane
+     * on the VALU:  cube: q[0..2] = center - side*0.5, q[3..5] = center + side*0.5 (the face planes
+     * `center.y + side * halfSide`, side = -1 / +1, and the bounds `center.x -+ halfSide`,
+     * rt/geometry.d:208-221);  sphere: q[0] = R * R (rt/geometry.d:99,129). */
+    double q[6];
 };
 
 enum NodeFlags : uint32_t {
@@ -93,7 +99,7 @@ struct alignas(16) DevMat {        /* 80 B */
     uint32_t texdata[8];
 };
 
-struct alignas(16) DevNode {       /* 416 B; the first 112 B are all a primitive under an identity matrix needs */
+struct alignas(16) DevNode {       /* 464 B; the first 160 B are all a primitive under an identity matrix needs */
     int32_t geom, shader;
     uint32_t flags, pad;
     double off[3];

@@ -38,39 +38,28 @@ __device__ __noinline__ double c2_atan2(double a, double b) { return atan2(a, b)
 __device__ __noinline__ double c2_asin(double a) { return asin(a); }
 __device__ __noinline__ double c2_sin(double a) { return sin(a); }
 __device__ __noinline__ double c2_cos(double a) { return cos(a); }
-/* Register budget, measured on MI355X (profiles/): with no hint hipcc takes all
- * 512 registers and runs one wave per SIMD (1.8x slower).  The CSG-free kernel
- * fits 4 waves/SIMD (128 VGPRs) without spills; the CSG kernels were fastest at
- * 3 waves/SIMD (168 VGPRs) while their LDS slabs capped a CU at 13 waves — see below. */
-#ifndef C2RT_OCC
-#if defined(C2RT_UNIT) && C2RT_UNIT == 0
-#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
-#elif defined(C2RT_UNIT) && C2RT_UNIT == 2
-#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(2, 2))) /* 198 VGPRs, no scratch */
-#elif defined(C2RT_UNIT) && C2RT_UNIT >= 3
-/* every nesting level keeps its stepping state live (all levels are inlined once): 215 (depth 3) /
- * 253 (depth 4) VGPRs without scratch — just inside the 256 that still allow two waves per SIMD, which
- * the shared hit stack (20 KiB per wave at depth 4 instead of 40 KiB of per-level slabs) now lets a CU hold */
+/* Register budget per kernel instance, as waves per SIMD (512 VGPRs per lane and SIMD: 128 at 4 waves,
+ * 168 at 3, 256 at 2).  With no hint hipcc takes all 512 registers and runs one wave per SIMD (1.8x
+ * slower).  Chosen per instance from the compiler's resource remarks (profiles/r02_resource_usage.txt)
+ * so that NO instance spills VGPRs to scratch, except where a measurement says otherwise:
+ *   depth 0 (no CSG), planes-only: 4 waves (111-127 VGPRs);
+ *   depth 1, at most one light: 4 waves — 128 VGPRs since the cube / sphere face tables moved to the upload
+ *     and the hit's lighting terms are evaluated before the shadow test (was 149 at 3 waves);
+ *   depth 1, several lights (the hit stays live across the light loop) and depth-1 DOF: 3 waves (144-162);
+ *   depth 2: 2 waves (176-202); depth 3 / 4: 2 waves (253-256, depth 4 spills ~45 VGPRs: measured faster
+ *     than 1 wave without spills, 19.8 -> 12 ms on csg_stress). */
+#ifndef C2RT_OCC_U1
+#define C2RT_OCC_U1 4
+#endif
 #ifndef C2RT_OCC_DEEP
 #define C2RT_OCC_DEEP 2
 #endif
-#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(C2RT_OCC_DEEP, C2RT_OCC_DEEP)))
-#else
-/* depth-1 CSG kernel: with 10 KiB slabs 16 waves fit a CU's LDS, and 4 waves/SIMD with 39 spilled VGPRs
- * (80 B of scratch per lane) are 2 % faster on multi-tap frames (lecture5 4K x5: 1.525 -> 1.490 ms) and 3 %
- * slower on the 1-tap 4K frame — but the spills put 760 MB of scratch writes per frame on HBM (WRITE_SIZE
- * 99.5 -> 861 MB): not worth it; 3 waves/SIMD (149 VGPRs, no scratch) stays until the kernel fits 128. */
-#ifndef C2RT_OCC_U1
-#define C2RT_OCC_U1 3
-#endif
-#define C2RT_OCC __attribute__((amdgpu_waves_per_eu(C2RT_OCC_U1, C2RT_OCC_U1)))
-#endif
-#endif
-#ifndef C2RT_OCC_DOF
-/* measured: the CSG-free DOF instance is faster at 4 waves/SIMD with 19 spilled
- * VGPRs (zaphod 4K x25: 6.83 ms) than at 3 without spills (7.05 ms) */
-#define C2RT_OCC_DOF C2RT_OCC
-#endif
+template <int LEVELS, bool DOF, bool MLC>
+constexpr int occ_of()
+{
+    return LEVELS == 0 ? 4 : (LEVELS == 1 ? ((DOF || MLC) ? 3 : C2RT_OCC_U1) : (LEVELS == 2 ? 2 : C2RT_OCC_DEEP));
+}
+#define C2RT_OCC_OF(L, D, M) __attribute__((amdgpu_waves_per_eu(occ_of<L, D, M>(), occ_of<L, D, M>())))
 #ifndef C2RT_XCD_SWIZZLE
 #define C2RT_XCD_SWIZZLE 1
 #endif
@@ -221,7 +210,7 @@ DEV bool sphere_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h, bool
     const D3 H = o - c;
     const double A = r.A;
     const double B = 2 * dot(H, d);
-    const double C = sqmag(H) - R * R;
+    const double C = sqmag(H) - G->q[0]; /* R * R, from the table */
     const double BB = B * B;
     const double Dscr = BB - 4 * A * C;
     /* Dscr < 0: no real root.  Or: outside the sphere and moving away — sqrt(Dscr) < B
@@ -260,16 +249,17 @@ DEV bool sphere_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h, bool
  * iff exactly one operand is and the numerator is non-zero), which skips the
  * division for every face behind the origin. */
 template <int NEED, int AXIS>
-DEV bool cube_sides(double oy, double dy, double cy, double ox, double dx, double cx,
-                    double oz, double dz, double cz, double halfSide, D3 o, D3 d, Hit &h, bool full)
+DEV bool cube_sides(double oy, double dy, double ylo, double yhi, double ox, double dx, double cx, double xlo, double xhi,
+                    double oz, double dz, double cz, double zlo, double zhi, D3 o, D3 d, Hit &h, bool full)
 {
     if (fabs(dy) < 1e-9) return false;
     bool found = false;
     const double den = -dy;
-    const double xlo = cx - halfSide, xhi = cx + halfSide, zlo = cz - halfSide, zhi = cz + halfSide;
+    /* face planes and bounds come from the table (DevGeom::q): `center + side * halfSide` and
+     * `center -+ halfSide` are the same for every ray */
 #pragma unroll
     for (int side = -1; side <= 1; side += 2) {
-        const double num = oy - (cy + side * halfSide);
+        const double num = oy - (side < 0 ? ylo : yhi);
         const bool negative = ((num < 0) & (den > 0)) | ((num > 0) & (den < 0));
         if (negative) continue;          /* mult < 0 */
         const double mult = num / den;
@@ -297,11 +287,11 @@ DEV bool cube_intersect(const DevGeom *G, int gid, const ORay &r, Hit &h, bool f
 {
     const D3 o = r.o, d = r.d;
     const D3 c = ld3(G->p);
-    const double halfSide = G->p[3] * 0.5;
+    const D3 lo = ld3(G->q), hi = ld3(G->q + 3);
     /* Y faces; X faces = project(1,0,2): (y,x,z); Z faces = project(0,2,1): (x,z,y) */
-    bool found = cube_sides<NEED, 1>(o.y, d.y, c.y, o.x, d.x, c.x, o.z, d.z, c.z, halfSide, o, d, h, full);
-    found |= cube_sides<NEED, 0>(o.x, d.x, c.x, o.y, d.y, c.y, o.z, d.z, c.z, halfSide, o, d, h, full);
-    found |= cube_sides<NEED, 2>(o.z, d.z, c.z, o.x, d.x, c.x, o.y, d.y, c.y, halfSide, o, d, h, full);
+    bool found = cube_sides<NEED, 1>(o.y, d.y, lo.y, hi.y, o.x, d.x, c.x, lo.x, hi.x, o.z, d.z, c.z, lo.z, hi.z, o, d, h, full);
+    found |= cube_sides<NEED, 0>(o.x, d.x, lo.x, hi.x, o.y, d.y, c.y, lo.y, hi.y, o.z, d.z, c.z, lo.z, hi.z, o, d, h, full);
+    found |= cube_sides<NEED, 2>(o.z, d.z, lo.z, hi.z, o.x, d.x, c.x, lo.x, hi.x, o.y, d.y, c.y, lo.y, hi.y, o, d, h, full);
     if (found) {
         if (NEED >= kPoint) h.g = gid;
         if (C2RT_WANT_FULL(NEED, full)) {
@@ -332,7 +322,7 @@ DEV bool geom_is_inside(const Ctx &cx, int gid, D3 p)
     const DevGeom *G = cx.geoms + gid;
     const int type = G->type;
     if (type == C2RT_GEOM_SPHERE) {
-        return sqmag(ld3(G->p) - p) < G->p[3] * G->p[3];
+        return sqmag(ld3(G->p) - p) < G->q[0];
     } else if (type == C2RT_GEOM_CUBE) {
         const double hs = G->p[3] * 0.5;
         return (fabs(p.x - G->p[0]) <= hs) & (fabs(p.y - G->p[1]) <= hs) & (fabs(p.z - G->p[2]) <= hs);
@@ -911,9 +901,11 @@ DEV F3 tex_color(const RenderParams &P, const Mat &m, double u, double v)
 /* shading — rt/shader.d:67-105,197-250                                  */
 /* ------------------------------------------------------------------ */
 
-/* MLC ("multi-light culling"): scenes with more than one light also derive the
- * culling mask of lights 1.. (per sample); single-light scenes run the instance
- * without that code. */
+/* MLC ("multi-light"): the instance for scenes with MORE THAN ONE light — the light loop, and the
+ * culling masks of lights 1.. derived per sample.  Scenes with at most one light (every scene the
+ * reference ships) run the MLC = false instance, in which the one light is straight-line code:
+ * nothing of the hit has to stay live for a next light, so the hit point, normal and view direction
+ * die before the shadow test (below). */
 template <int LEVELS, bool MLC, bool PO>
 DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const Hit &h, uint32_t &shadow_rays)
 {
@@ -922,27 +914,32 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const 
     const F3 diffuse = mat.tex_type >= 0 ? tex_color(P, mat, h.u, h.v) : mat.color;
     F3 lightContrib = mkf(P.ambient[0], P.ambient[1], P.ambient[2]);
     F3 specular = mkf(0, 0, 0);
-    const uint32_t nl = P.n_lights;
+    const uint32_t nl = MLC ? P.n_lights : (P.n_lights ? 1u : 0u);
     for (uint32_t l = 0; l < nl; ++l) {
         const DevLight *L = P.lights + l;
         F3 avgColor = mkf(0, 0, 0), avgSpecular = mkf(0, 0, 0);
         if (L->lit) {
             const D3 lightPos = ld3(L->pos);
             shadow_rays += 1;
-            if (test_visibility<LEVELS, PO>(cx, h.p + N * 1e-6, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.block, cx.lane, l) : 0xFFFFFFFFu), l == 0 && cx.shadow_ground_only)) {
-                const F3 lightColor = ldf3(L->color);
-                const D3 lightDir = normalized(lightPos - h.p);
-                const double cosTheta = dot(lightDir, N);
-                const F3 baseLight = lightColor / (float)sqmag(h.p - lightPos);
+            /* Everything the lit branch reads from the hit is evaluated BEFORE the visibility test (same
+             * operations on the same operands, so the same bits; a shadowed sample wastes two
+             * normalisations): across the test — the register peak of the kernel, a CSG walk inside
+             * a node loop — only cosTheta, baseLight and cosGamma stay live instead of p, N and rd. */
+            const D3 from = h.p + N * 1e-6;
+            const D3 lightDir = normalized(lightPos - h.p);
+            const double cosTheta = dot(lightDir, N);
+            const F3 baseLight = ldf3(L->color) / (float)sqmag(h.p - lightPos);
+            double cosGamma = 0;
+            if (phong) {
+                /* reflect(-lightDir, N) — rt/imported_types.d:62-67 */
+                const D3 ml = -lightDir;
+                const D3 R = normalized(ml - N * (2 * dot(ml, N)));
+                cosGamma = dot(R, -rd);
+            }
+            if (test_visibility<LEVELS, PO>(cx, from, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.block, cx.lane, l) : 0xFFFFFFFFu), l == 0 && cx.shadow_ground_only)) {
                 if (cosTheta > 0) avgColor = avgColor + baseLight * (float)cosTheta;
-                if (phong) {
-                    /* reflect(-lightDir, N) — rt/imported_types.d:62-67 */
-                    const D3 ml = -lightDir;
-                    const D3 R = normalized(ml - N * (2 * dot(ml, N)));
-                    const double cosGamma = dot(R, -rd);
-                    if (cosGamma > 0)
-                        avgSpecular = avgSpecular + baseLight * (float)c2_pow(cosGamma, mat.exponent) * mat.strength;
-                }
+                if (phong & (cosGamma > 0))
+                    avgSpecular = avgSpecular + baseLight * (float)c2_pow(cosGamma, mat.exponent) * mat.strength;
             }
         }
         /* `/ numSamples` with numSamples == 1 (rt/light.d:56-59) is exact */
@@ -1349,25 +1346,25 @@ DEV void render_body(const RenderParams &P)
 }
 
 template <int LEVELS, bool DOF, bool MLC>
-__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel(const RenderParams P)
+__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, DOF, MLC) render_kernel(const RenderParams P)
 {
     render_body<LEVELS, DOF, MLC, false>(P);
 }
 
 /* The depth-of-field / stereo instance carries the lens sampling state on top of
  * the tracer's and has its own register budget (C2RT_OCC_DOF). */
-template <int LEVELS>
-__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_DOF render_kernel_dof(const RenderParams P)
+template <int LEVELS, bool MLC>
+__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, true, MLC) render_kernel_dof(const RenderParams P)
 {
-    render_body<LEVELS, true, false, false>(P);
+    render_body<LEVELS, true, MLC, false>(P);
 }
 
 /* Scenes made of axis planes only (RenderParams::planes_only — lecture4.sdl, zaphod.sdl): the
  * instances in which a plane's miss is decided before the ray is normalised (plane_points_away). */
 template <bool DOF>
-__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC render_kernel_planes(const RenderParams P)
+__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(0, DOF, false) render_kernel_planes(const RenderParams P)
 {
-    render_body<0, DOF, false, true>(P); /* planes have no boxes: no culling masks, hence no MLC */
+    render_body<0, DOF, false, true>(P); /* at most one light (launch_render_level); planes have no boxes, hence no culling masks */
 }
 
 /* renderPixel — rt/renderer.d:46-57: one lane, one sample, full trace result */
@@ -1391,7 +1388,7 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.ground_y = 0;
     Counters cnt = {0, 0};
     const uint64_t pixel = (uint64_t)P.probe_y * P.width + (uint64_t)P.probe_x;
-    const F3 c = render_sample<LEVELS, DOF, false, false>(P, cx, (double)P.probe_x, (double)P.probe_y, 1, 1, pixel, 0, cnt, P.probe_out);
+    const F3 c = render_sample<LEVELS, DOF, true, false>(P, cx, (double)P.probe_x, (double)P.probe_y, 1, 1, pixel, 0, cnt, P.probe_out); /* MLC: any number of lights (n_cull = 0: no masks) */
     P.probe_out->color[0] = c.r;
     P.probe_out->color[1] = c.g;
     P.probe_out->color[2] = c.b;
@@ -1462,7 +1459,7 @@ int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, vo
     const dim3 grid(p.retry_mode ? 2048u : p.blocks_x * tiles_y_pad), block(kBlockThreads);
     const size_t lds = (size_t)p.csg_cap * kCsgLdsPerEntry * kWavesPerBlock;
 #if C2RT_UNIT == 0
-    if (p.planes_only) {
+    if (p.planes_only && p.n_lights <= 1) { /* (planes + several lights: the general instances below) */
         if (dof_or_stereo)
             hipLaunchKernelGGL((render_kernel_planes<true>), grid, block, lds, s, p);
         else
@@ -1470,9 +1467,12 @@ int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, vo
         return (int)hipGetLastError();
     }
 #endif
-    if (dof_or_stereo)
-        hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT>), grid, block, lds, s, p);
-    else if (p.n_cull_lights > 1)
+    if (dof_or_stereo) {
+        if (p.n_lights > 1)
+            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, true>), grid, block, lds, s, p);
+        else
+            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, false>), grid, block, lds, s, p);
+    } else if (p.n_lights > 1)
         hipLaunchKernelGGL((render_kernel<C2RT_UNIT, false, true>), grid, block, lds, s, p);
     else
         hipLaunchKernelGGL((render_kernel<C2RT_UNIT, false, false>), grid, block, lds, s, p);
