@@ -167,6 +167,9 @@ struct Ctx {
     /* the ground plane (RenderParams::ground_node) is the ONLY node left in shadow_mask0: the tile's
      * shadow rays towards light 0 are decided by plane_points_away alone, without building a ray */
     bool shadow_ground_only;
+    /* the ground plane is the ONLY node left in primary_mask: the tile's primary rays take the
+     * straight-line ground trace (raytrace) instead of the node loop */
+    bool primary_ground_only;
     double ground_y;
 };
 
@@ -659,9 +662,11 @@ DEV bool plane_points_away(const DevNode *N, D3 from, D3 raw)
     return sane & (((oy > y) & up) | ((oy < y) & down));
 }
 
-/* Node.intersect; `best.dist` is data.dist (world units) in and out. */
+/* Node.intersect; `best.dist` is data.dist (world units) in and out.  `last` (wave-uniform): no
+ * further node will be tested against this ray, so nobody reads the updated best.dist again (it only
+ * serves as the next node's limit) and its division is skipped. */
 template <int LEVELS, int NEED>
-DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &best)
+DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &best, bool last = false)
 {
     const uint32_t flags = N->flags;
     ORay rc;
@@ -688,7 +693,7 @@ DEV bool node_intersect(const Ctx &cx, const DevNode *N, const RayW &ray, Hit &b
     h.dist = best.dist * len;
     if (!geom_intersect_rec<LEVELS, NEED>(cx, G, gid, rc, h, false, 0)) return false;
     if (NEED == kBool) return true;
-    best.dist = h.dist / len;
+    if (!last) best.dist = h.dist / len;
     best.g = h.g;
     best.u = h.u;
     best.v = h.v;
@@ -926,9 +931,15 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const 
              * normalisations): across the test — the register peak of the kernel, a CSG walk inside
              * a node loop — only cosTheta, baseLight and cosGamma stay live instead of p, N and rd. */
             const D3 from = h.p + N * 1e-6;
-            const D3 lightDir = normalized(lightPos - h.p);
+            /* squaredMagnitude(p - lightPos) == squaredMagnitude(lightPos - p) bit for bit (IEEE a - b is
+             * exactly -(b - a), and the squares drop the sign): one vector, one sum of squares for both
+             * normalize(lightPos - p) and the 1/r^2 term */
+            const D3 lv = lightPos - h.p;
+            const double r2 = sqmag(lv);
+            const double rinv = 1.0 / sqrt(r2);
+            const D3 lightDir = mk(lv.x * rinv, lv.y * rinv, lv.z * rinv);
             const double cosTheta = dot(lightDir, N);
-            const F3 baseLight = ldf3(L->color) / (float)sqmag(h.p - lightPos);
+            const F3 baseLight = ldf3(L->color) / (float)r2;
             double cosGamma = 0;
             if (phong) {
                 /* reflect(-lightDir, N) — rt/imported_types.d:62-67 */
@@ -1080,7 +1091,6 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 raw, Counters &cn
         }
     }
     const D3 d = normalized(raw);
-    const RayW ray = make_ray(o, d);
     Hit best;
     best.dist = 1e99;
     best.p = best.n = mk(0, 0, 0);
@@ -1089,12 +1099,50 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 raw, Counters &cn
     best.uv_pending = false;
     best.axis_n = false;
     int closest = -1;
-    for (; n < nn; n = next_node(cx.primary_mask, n + 1)) /* scalar loop, file order */
-        if (node_intersect<LEVELS, kFull>(cx, P.nodes + n, ray, best)) closest = (int)n;
-    /* Sphere u,v are read only by textured shaders (and the probe) */
     Mat mat;
-    load_mat(P.nodes, closest, mat);
-    if (closest >= 0 && best.uv_pending && (probe || mat.tex_type >= 0)) finish_uv(best);
+    if (!PO && !probe && cx.primary_ground_only) { /* wave-uniform */
+        /* Ground tile (most of a frame that looks at a floor): the node loop collapses to Node.intersect +
+         * Plane.intersect on ONE node known to be a Plane under the identity matrix with zero offset
+         * (RenderParams::ground_node) — the same operations on the same operands as the general path
+         * (node_intersect, plane_intersect), minus the loop, the flag tests, the per-lane record merge and
+         * the per-lane shading-input fetch: the node is the same for every lane, so its DevMat stays in
+         * scalar registers. */
+        const DevNode *N = P.nodes + P.ground_node;
+        const double len = mag(d);                       /* make_ray: |d|, d * (1/|d|) */
+        const double inv = 1.0 / len;
+        const D3 dn = mk(d.x * inv, d.y * inv, d.z * inv);
+        const double y = N->g.p[0], limit = N->g.p[1];
+        const bool away = ((o.y > y) & (dn.y > -1e-9)) | ((o.y < y) & (dn.y < 1e-9));
+        const double mult = (o.y - y) / -dn.y;
+        const D3 p = o + dn * mult;
+        const bool miss = away | (mult > 1e99 * len) | (fabs(p.x) > limit) | (fabs(p.z) > limit);
+        if (!miss) {
+            closest = P.ground_node;
+            best.p = p;
+            best.n = mk(0, 1, 0);
+            best.u = p.x;
+            best.v = p.z;
+            best.g = N->geom;
+        }
+        const DevMat *M = &N->mat;
+        mat.shader_type = M->shader_type;
+        mat.tex_type = M->tex_type;
+        mat.tex = M->tex;
+        mat.strength = M->strength;
+        mat.color = ldf3(M->color);
+        mat.exponent = M->exponent;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mat.td[i] = M->texdata[i];
+    } else {
+        const RayW ray = make_ray(o, d);
+        for (uint32_t nx; n < nn; n = nx) { /* scalar loop, file order */
+            nx = next_node(cx.primary_mask, n + 1);
+            if (node_intersect<LEVELS, kFull>(cx, P.nodes + n, ray, best, nx >= nn && !probe)) closest = (int)n;
+        }
+        /* Sphere u,v are read only by textured shaders (and the probe) */
+        load_mat(P.nodes, closest, mat);
+        if (closest >= 0 && best.uv_pending && (probe || mat.tex_type >= 0)) finish_uv(best);
+    }
     if (probe) {
         probe->closest_node = closest;
         probe->leaf_geom = closest >= 0 ? best.g : -1;
@@ -1203,7 +1251,7 @@ DEV void render_tile(const RenderParams &P, const uint32_t b)
      * ballot makes the wave-uniform masks — before any lane leaves, so that every
      * node has its lane. */
     uint32_t pmask = 0xFFFFFFFFu, smask0 = 0xFFFFFFFFu;
-    bool ground_only = false;
+    bool ground_only = false, primary_ground = false;
     if constexpr (!DOF) {
         if (P.n_cull) {
             int tx0, ty0, ty1;
@@ -1221,6 +1269,7 @@ DEV void render_tile(const RenderParams &P, const uint32_t b)
             const int gnode = P.ground_node;
             const uint32_t nn = P.n_nodes;
             if (gnode >= 0 && nn <= 32u && (pmask & (0xFFFFFFFFu >> (32u - nn))) == (1u << gnode)) {
+                primary_ground = true;
                 const D3 pos = ld3(P.cam.pos), ul = ld3(P.cam.up_left), du = ld3(P.cam_du), dv = ld3(P.cam_dv);
                 const double gy = P.ground_y;
                 /* lane k & 3 intersects corner k's ray with the plane; lanes 0..3 are then read back */
@@ -1269,6 +1318,7 @@ DEV void render_tile(const RenderParams &P, const uint32_t b)
     cx.primary_mask = pmask;
     cx.shadow_mask0 = smask0;
     cx.shadow_ground_only = ground_only;
+    cx.primary_ground_only = primary_ground;
     cx.ground_y = P.ground_y;
     Counters cnt = {0, 0};
     /* prepassOnly (rt/renderer.d:110-130): the pixel shows the sample of the
@@ -1385,6 +1435,7 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.primary_mask = 0xFFFFFFFFu;
     cx.shadow_mask0 = 0xFFFFFFFFu;
     cx.shadow_ground_only = false;
+    cx.primary_ground_only = false;
     cx.ground_y = 0;
     Counters cnt = {0, 0};
     const uint64_t pixel = (uint64_t)P.probe_y * P.width + (uint64_t)P.probe_x;
