@@ -150,7 +150,13 @@ enum Need {
 /* what the trace needs below the shading level: table bases (SGPRs), the
  * wave's CSG slabs and the lane.  Deliberately NOT a pointer to the kernel
  * arguments (which would have to be materialised in scratch if it escaped). */
+/* The kernel-argument segment (the by-value RenderParams block), as handed down from the __global__
+ * entry point: helpers must not fetch it themselves (__builtin_amdgcn_kernarg_segment_ptr() is only
+ * meaningful in the kernel function; an out-of-line callee would read garbage). */
+typedef const RenderParams __attribute__((address_space(4))) *KArgs;
+
 struct Ctx {
+    KArgs kargs;
     const DevGeom *geoms;
     const DevNode *nodes;
     uint32_t n_nodes;
@@ -746,11 +752,10 @@ DEV void tile_bounds(const RenderParams &P, uint32_t b, int &tx0, int &ty0, int 
 }
 
 /* this lane's node rectangle (lane n stands for node n), read from the kernel-argument segment */
-DEV void lane_rect(const RenderParams &P, int lane, bool &mine, int &r0, int &r1, int &r2, int &r3)
+DEV void lane_rect(const RenderParams &P, KArgs K, int lane, bool &mine, int &r0, int &r1, int &r2, int &r3)
 {
     typedef const int __attribute__((address_space(4))) *KInt;
-    KInt rects = (KInt)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() +
-                        __builtin_offsetof(RenderParams, cull_rect));
+    KInt rects = (KInt)((const char __attribute__((address_space(4))) *)K + __builtin_offsetof(RenderParams, cull_rect));
     mine = (uint32_t)lane < P.n_cull; /* lanes >= n_cull stand for "always test" */
     const int ln = mine ? lane : 0;
     r0 = rects[4 * ln + 0];
@@ -764,7 +769,7 @@ DEV void lane_rect(const RenderParams &P, int lane, bool &mine, int &r0, int &r1
  * plane of the pyramid while the light is on the inner side of that plane is in a
  * half space none of those segments enters.  Lanes that are not active (missed,
  * left the frame) cannot vote: their nodes stay "may occlude". */
-DEV uint32_t shadow_cull_mask(const RenderParams &P, uint32_t block, int lane, uint32_t l)
+DEV uint32_t shadow_cull_mask(const RenderParams &P, KArgs K, uint32_t block, int lane, uint32_t l)
 {
     if (!P.n_cull || l >= P.n_cull_lights) return 0xFFFFFFFFu;
     int tx0, ty0, ty1;
@@ -773,7 +778,7 @@ DEV uint32_t shadow_cull_mask(const RenderParams &P, uint32_t block, int lane, u
     const int sx1 = tx0 + kTileW + 1, sy1 = ty1 + 1;
     bool mine;
     int r0, r1, r2, r3;
-    lane_rect(P, lane, mine, r0, r1, r2, r3);
+    lane_rect(P, K, lane, mine, r0, r1, r2, r3);
     const int *sd = P.light_side[l];
     const bool in_left = tx0 >= sd[0] && tx0 <= sd[1];   /* light on the ">= tx0" side of the left plane */
     const bool in_right = sx1 >= sd[2] && sx1 <= sd[3];  /* light on the "<= sx1" side of the right plane */
@@ -947,7 +952,7 @@ DEV F3 shade(const RenderParams &P, const Ctx &cx, const Mat &mat, D3 rd, const 
                 const D3 R = normalized(ml - N * (2 * dot(ml, N)));
                 cosGamma = dot(R, -rd);
             }
-            if (test_visibility<LEVELS, PO>(cx, from, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.block, cx.lane, l) : 0xFFFFFFFFu), l == 0 && cx.shadow_ground_only)) {
+            if (test_visibility<LEVELS, PO>(cx, from, lightPos, l == 0 ? cx.shadow_mask0 : (MLC ? shadow_cull_mask(P, cx.kargs, cx.block, cx.lane, l) : 0xFFFFFFFFu), l == 0 && cx.shadow_ground_only)) {
                 if (cosTheta > 0) avgColor = avgColor + baseLight * (float)cosTheta;
                 if (phong & (cosGamma > 0))
                     avgSpecular = avgSpecular + baseLight * (float)c2_pow(cosGamma, mat.exponent) * mat.strength;
@@ -1221,7 +1226,7 @@ __constant__ double k_aa_y[5] = {0.0, 0.3, 0.0, 0.6, 0.6};
  * pixel).  One workgroup = one wavefront = one 8x8 tile.
  */
 template <int LEVELS, bool DOF, bool MLC, bool PO>
-DEV void render_tile(const RenderParams &P, const uint32_t b)
+DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
 {
     extern __shared__ __align__(16) char lds_all[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -1258,9 +1263,9 @@ DEV void render_tile(const RenderParams &P, const uint32_t b)
             tile_bounds(P, b, tx0, ty0, ty1);
             bool mine;
             int r0, r1, r2, r3;
-            lane_rect(P, lane, mine, r0, r1, r2, r3);
+            lane_rect(P, K, lane, mine, r0, r1, r2, r3);
             pmask = (uint32_t)__ballot(!mine || !(r2 <= tx0 || r0 >= tx0 + kTileW || r3 <= ty0 || r1 > ty1));
-            smask0 = shadow_cull_mask(P, b, lane, 0);
+            smask0 = shadow_cull_mask(P, K, b, lane, 0);
             /* Ground-plane refinement (RenderParams::ground_node): if this tile's primary rays can only
              * reach the ground plane, all its hit points lie inside the tile's footprint on that plane
              * — the convex image of the pixel rectangle (+1 px all round; the AA taps reach 0.6 px),
@@ -1310,6 +1315,7 @@ DEV void render_tile(const RenderParams &P, const uint32_t b)
     cx.geoms = P.geoms;
     cx.nodes = P.nodes;
     cx.n_nodes = P.n_nodes;
+    cx.kargs = K;
     cx.lds = lds;
     cx.lane = lane;
     cx.csg_cap = (int)P.csg_cap;
@@ -1376,7 +1382,7 @@ DEV void render_tile(const RenderParams &P, const uint32_t b)
  * the nested-CSG instances) a fixed grid walks the list of tiles whose hit stacks overflowed.
  * Either way the tile code is inlined once. */
 template <int LEVELS, bool DOF, bool MLC, bool PO>
-DEV void render_body(const RenderParams &P)
+DEV void render_body(const RenderParams &P, KArgs K)
 {
     if constexpr (LEVELS >= 2) {
         uint32_t i = blockIdx.x;
@@ -1387,18 +1393,18 @@ DEV void render_body(const RenderParams &P)
                 if (i >= (listed < P.retry_max ? listed : P.retry_max)) break;
                 b = P.retry_list[1 + i];
             }
-            render_tile<LEVELS, DOF, MLC, PO>(P, b);
+            render_tile<LEVELS, DOF, MLC, PO>(P, K, b);
             i += gridDim.x;
         } while (P.retry_mode);
     } else {
-        render_tile<LEVELS, DOF, MLC, PO>(P, blockIdx.x);
+        render_tile<LEVELS, DOF, MLC, PO>(P, K, blockIdx.x);
     }
 }
 
 template <int LEVELS, bool DOF, bool MLC>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, DOF, MLC) render_kernel(const RenderParams P)
 {
-    render_body<LEVELS, DOF, MLC, false>(P);
+    render_body<LEVELS, DOF, MLC, false>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 /* The depth-of-field / stereo instance carries the lens sampling state on top of
@@ -1406,7 +1412,7 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, DOF, MLC) r
 template <int LEVELS, bool MLC>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, true, MLC) render_kernel_dof(const RenderParams P)
 {
-    render_body<LEVELS, true, MLC, false>(P);
+    render_body<LEVELS, true, MLC, false>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 /* Scenes made of axis planes only (RenderParams::planes_only — lecture4.sdl, zaphod.sdl): the
@@ -1414,7 +1420,7 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, true, MLC) 
 template <bool DOF>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(0, DOF, false) render_kernel_planes(const RenderParams P)
 {
-    render_body<0, DOF, false, true>(P); /* at most one light (launch_render_level); planes have no boxes, hence no culling masks */
+    render_body<0, DOF, false, true>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr()); /* at most one light (launch_render_level); planes have no boxes, hence no culling masks */
 }
 
 /* renderPixel — rt/renderer.d:46-57: one lane, one sample, full trace result */
@@ -1427,6 +1433,7 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.geoms = P.geoms;
     cx.nodes = P.nodes;
     cx.n_nodes = P.n_nodes;
+    cx.kargs = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     cx.lds = lds;
     cx.lane = 0;
     cx.csg_cap = (int)P.csg_cap;
