@@ -1105,7 +1105,7 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 raw, Counters &cn
     best.axis_n = false;
     int closest = -1;
     Mat mat;
-    if (!PO && !probe && cx.primary_ground_only) { /* wave-uniform */
+    if (!probe && cx.primary_ground_only) { /* wave-uniform */
         /* Ground tile (most of a frame that looks at a floor): the node loop collapses to Node.intersect +
          * Plane.intersect on ONE node known to be a Plane under the identity matrix with zero offset
          * (RenderParams::ground_node) — the same operations on the same operands as the general path
@@ -1298,6 +1298,10 @@ DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
             }
         }
     }
+
+    /* a scene whose only node is the ground plane (zaphod.sdl, lecture4.sdl): every tile is a ground
+     * tile, wherever its rays start (depth of field, stereo) */
+    if (P.n_nodes == 1u && P.ground_node == 0) primary_ground = true;
 
     const uint32_t x = tcol * kTileW + (lane % kTileW);
     const uint32_t lr0 = trow * kTileH + (lane / kTileW); /* row within this launch */

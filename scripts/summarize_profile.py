@@ -16,13 +16,23 @@ with open(os.path.join(src, "trace", "trace_kernel_stats.csv")) as f:
     rows = list(csv.DictReader(f))
 summ["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows]
 with open(os.path.join(src, "trace", "trace_kernel_trace.csv")) as f:
-    tr = [r for r in csv.DictReader(f) if KERNEL in r["Kernel_Name"]]
+    tr_all = [r for r in csv.DictReader(f) if KERNEL in r["Kernel_Name"]]
+# Nested-CSG scenes launch the frame kernel twice per frame: the whole grid with the reduced hit stack,
+# then a fixed 2048-workgroup grid over the tiles that overflowed it (usually none).  The frame launch
+# is the one with the larger grid; the retry launches are reported beside it.
+main_grid = max(int(r["Grid_Size_X"]) for r in tr_all)
+tr = [r for r in tr_all if int(r["Grid_Size_X"]) == main_grid]
+retry = [r for r in tr_all if int(r["Grid_Size_X"]) != main_grid]
 durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
 summ["kernel"] = tr[0]["Kernel_Name"]
 summ["launches"] = len(durs)
 timed = durs[-20:]  # the last 20 launches are bench.py's timed steps
 summ["avg_duration_us_timed"] = statistics.mean(timed) / 1e3
 summ["median_duration_us_timed"] = statistics.median(timed) / 1e3
+if retry:
+    rd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in retry][-20:]
+    summ["retry_launches"] = len(retry)
+    summ["retry_avg_duration_us_timed"] = statistics.mean(rd) / 1e3
 for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X"):
     summ[k] = tr[0][k]
 
@@ -34,15 +44,20 @@ for sub in sorted(os.listdir(src)):
         continue
     with open(p) as f:
         for r in csv.DictReader(f):
-            if KERNEL in r["Kernel_Name"]:
+            if KERNEL in r["Kernel_Name"] and int(r["Grid_Size"]) == main_grid:
                 counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 pmc_dur.setdefault(sub, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 summ["pmc_per_launch_avg"] = {k: statistics.mean(v[-20:]) for k, v in counters.items()}
 summ["pmc_pass_avg_duration_us"] = {k: statistics.mean(v[-20 * (len(v) // 24 or 1):]) / 1e3 for k, v in pmc_dur.items()}
 c = summ["pmc_per_launch_avg"]
 d = {}
-if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
-    d["valu_active_over_busy"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_BUSY_CYCLES"]
+if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+    # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles summed over the chip's 1024 SIMDs;
+    # GRBM_GUI_ACTIVE is the busy-cycle count summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS section)
+    simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+    d["valu_busy_fraction"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles
+    d["resident_waves_per_simd"] = 4.0 * c["SQ_WAVE_CYCLES"] / simd_cycles
+    d["clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (statistics.mean(pmc_dur.get("pmc_sq2", [0])[-20:]) or 1)
 if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
     d["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
 if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
@@ -73,7 +88,8 @@ if workload and "hbm_bytes_per_launch" in d and "SQ_INSTS_VALU" in c:
         "hbm_bytes_per_launch": 2 * fetch + write,
         "valu_insts_per_launch": c["SQ_INSTS_VALU"],
         "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
-        "valu_busy_fraction": d.get("valu_active_over_busy"),
+        "valu_busy_fraction": d.get("valu_busy_fraction"),
+        "resident_waves_per_simd": d.get("resident_waves_per_simd"),
         "lane_utilisation": d.get("lane_utilisation"),
         "valu_insts_per_wave": d.get("valu_insts_per_wave"),
         "kernel_avg_us": summ["avg_duration_us_timed"],
