@@ -221,3 +221,53 @@ def ground_scene_sdl(seed):
         "  Shaders {\n    " + "\n    ".join(shaders) + "\n  }",
         "  Nodes {\n    " + "\n    ".join(nodes) + "\n  }",
         "}", ""])
+
+
+def many_nodes_scene_sdl(seed, n_objects):
+    """A ground plane plus `n_objects` small spheres / cubes / depth-1 CSG objects scattered over it (every
+    third one under a scaled / translated node): scenes whose node count crosses the 32-node width of the
+    per-tile culling masks (kMaxCullNodes) — nodes 32.. are always tested, nodes below it may be culled."""
+    r = random.Random(40_000 + 1000 * n_objects + seed)
+    geoms = ['Plane "ground" { y 0 }']
+    nodes = ['Node "n0" { geometry "ground"; shader "s%d" }' % r.choice([0, 2, 3])]
+    for i in range(n_objects):
+        kind = r.choice(["Sphere", "Sphere", "Cube", "Csg"])
+        size = r.uniform(3, 9)
+        c = "%.6g %.6g %.6g" % (r.uniform(-110, 110), r.uniform(0.4, 2.5) * size, r.uniform(-30, 190))
+        if kind == "Sphere":
+            geoms.append('Sphere "g%d" { center %s; R %.6g }' % (i, c, size))
+        elif kind == "Cube":
+            geoms.append('Cube "g%d" { center %s; side %.6g }' % (i, c, 2 * size))
+        else:
+            geoms.append('Cube "g%da" { center %s; side %.6g }' % (i, c, 2 * size))
+            geoms.append('Sphere "g%db" { center %s; R %.6g }' % (i, c, size * r.uniform(0.9, 1.35)))
+            geoms.append('%s "g%d" { left "g%da"; right "g%db" }' % (r.choice(["CsgDiff", "CsgInter", "CsgUnion"]), i, i, i))
+        xf = ""
+        if i % 3 == 1:
+            xf += "; scale %s" % _v(r, 0.7, 1.5)
+        if i % 3 == 2:
+            xf += "; translate %s" % _v(r, -12, 12)
+        nodes.append('Node "n%d" { geometry "g%d"; shader "s%d"%s }' % (i + 1, i, r.randint(0, 5), xf))
+    textures = ['Checker "chk" { color1 %s; color2 %s; size %.6g }' % (_v(r, 0, 1), _v(r, 0, 1), r.uniform(6, 30)),
+                'Procedure2 "proc" { freqU %s; freqV %s; colorU { color %s; color %s; color %s }; colorV { color %s; color %s; color %s } }'
+                % (_v(r, 0.01, 0.5), _v(r, 0.01, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5), _v(r, 0, 0.5)),
+                'BitmapTexture "bmp" { file "floor.bmp"; scaling %.6g }' % r.uniform(0.005, 0.05)]
+    shaders = ['Lambert "s0" { texture "chk" }', 'Lambert "s1" { texture "proc" }', 'Lambert "s2" { texture "bmp" }',
+               'Lambert "s3" { color %s }' % _v(r, 0.1, 1),
+               'Phong "s4" { color %s; exponent %.6g; strength %.6g }' % (_v(r, 0.1, 1), r.uniform(2, 90), r.uniform(0.2, 1)),
+               'Phong "s5" { texture "bmp"; exponent %.6g }' % r.uniform(5, 40)]
+    lights = ['PointLight "l0" { pos %.6g %.6g %.6g; color 1 1 1; power 90000 }' % (r.uniform(-150, 150), r.uniform(90, 300), r.uniform(-100, 200))]
+    if seed % 2:
+        lights.append('PointLight "l1" { pos %s; color %s; power 30000 }' % (_v(r, -150, 150), _v(r, 0.3, 1)))
+    cam = "Camera { pos %.6g %.6g %.6g; yaw %.6g; pitch %.6g; roll %.6g; fov %.6g }" % (
+        r.uniform(-20, 20), r.uniform(40, 110), r.uniform(-150, -80), r.uniform(-12, 12), r.uniform(-40, -15), r.uniform(-4, 4), r.uniform(55, 90))
+    return "\n".join([
+        "Scene {", '  Name "many%d_%d"' % (n_objects, seed),
+        "  GlobalSettings { frameWidth 320; frameHeight 180; AAEnabled false; ambientLightColor %s }" % _v(r, 0, 0.2),
+        "  " + cam,
+        "  Lights {\n    " + "\n    ".join(lights) + "\n  }",
+        "  Geometries {\n    " + "\n    ".join(geoms) + "\n  }",
+        "  Textures {\n    " + "\n    ".join(textures) + "\n  }",
+        "  Shaders {\n    " + "\n    ".join(shaders) + "\n  }",
+        "  Nodes {\n    " + "\n    ".join(nodes) + "\n  }",
+        "}", ""])

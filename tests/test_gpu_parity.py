@@ -683,6 +683,90 @@ print("ok")
     assert p.returncode == 0 and "ok" in p.stdout, p.stdout + p.stderr
 
 
+def _check_scene_text(gpu_ctx, path, text, size=None, taps=None):
+    path.write_text(text)
+    scene = c2.parseSceneFromFile(str(path))
+    if size:
+        scene.setFrameSize(*size)
+    cam = scene.beginFrame()
+    opts = scene.renderOpts(count_rays=1) if taps is None else scene.renderOpts(count_rays=1, taps=taps)
+    gpu_ctx.uploadScene(scene.desc)
+    a = gpu_ctx.renderFrame(cam, opts)
+    rays = gpu_ctx.rayStats()
+    st = {}
+    ref = orc.render_frame(scene.desc, cam, opts, 0, st)
+    assert np.array_equal(np.isnan(a), np.isnan(ref)), path
+    md, nbad, nne = maxdiff(a, ref)
+    assert md <= TOL and nbad == 0, (str(path), md)
+    assert rays == (st["primary"], st["shadow"]), path
+    return nne, scene.desc.contents.n_nodes
+
+
+@pytest.mark.parametrize("n_objects", [30, 31, 32, 33, 47, 63, 64, 90])
+def test_many_node_scenes_cross_the_cull_mask_boundary(gpu_ctx, tmp_path, scenes_dir, n_objects):
+    """Ground plane + 30..90 objects: 31..91 nodes.  The per-tile culling masks cover nodes 0..31
+    (kMaxCullNodes); nodes from 32 on are always tested (next_node's n >= 32 path), and the ground
+    refinement needs n_nodes <= 32.  Frames and ray counts must equal the oracle's on both sides of
+    that boundary, with one and two lights, at 320x180 and 5 taps for one seed."""
+    import shutil
+
+    from scene_fuzz import many_nodes_scene_sdl
+
+    shutil.copy(os.path.join(scenes_dir, "floor.bmp"), tmp_path / "floor.bmp")
+    differing = 0
+    for seed in range(3):
+        nne, nn = _check_scene_text(gpu_ctx, tmp_path / ("many%d_%d.sdl" % (n_objects, seed)), many_nodes_scene_sdl(seed, n_objects),
+                                    taps=5 if seed == 2 else 1)
+        assert nn == n_objects + 1
+        differing += nne
+    print("many-node fuzz (%d objects): %d differing floats" % (n_objects, differing))
+
+
+def test_fuzz_scenes_at_larger_frames(gpu_ctx, tmp_path, scenes_dir):
+    """20 fuzz scenes (general CSG trees, ground-plane scenes, many-lights, planes-only, many-node) at
+    640x360 .. 800x450: thousands of tiles per frame instead of the 108 of the small fuzz frames, so
+    that the per-tile culling masks, the dispatch rotation and the XCD tile map are exercised the
+    way a full frame exercises them."""
+    import shutil
+
+    from scene_fuzz import ground_scene_sdl, many_lights_scene_sdl, many_nodes_scene_sdl, planes_scene_sdl, random_scene_sdl
+
+    shutil.copy(os.path.join(scenes_dir, "floor.bmp"), tmp_path / "floor.bmp")
+    cases = [("gen%d" % s, random_scene_sdl(1000 + s, max_depth=3 + s % 2), (640, 360)) for s in range(6)]
+    cases += [("ground%d" % s, ground_scene_sdl(500 + s), (800, 450)) for s in range(6)]
+    cases += [("lights%d" % s, many_lights_scene_sdl(700 + s), (640, 360)) for s in range(3)]
+    cases += [("planes%d" % s, planes_scene_sdl(900 + s), (723, 407)) for s in range(3)]
+    cases += [("many%d" % s, many_nodes_scene_sdl(10 + s, 40 + 20 * s), (640, 360)) for s in range(2)]
+    assert len(cases) == 20
+    differing = 0
+    for name, text, size in cases:
+        nne, _ = _check_scene_text(gpu_ctx, tmp_path / (name + ".sdl"), text, size=size)
+        differing += nne
+    print("large-frame fuzz: %d differing floats over 20 scenes" % differing)
+
+
+@pytest.mark.parametrize("scene_file,w,h,taps,rays", [("zaphod.sdl", 3840, 2160, 4, None), ("lecture5.sdl", 7680, 4320, 4, 132710400)])
+def test_baseline_configs_4_and_5_full_frames(gpu_ctx, scene_file, w, h, taps, rays):
+    """BASELINE configs[3] (zaphod.sdl 3840x2160, "4 spp", DOF off) and configs[4]'s frame (lecture5.sdl
+    7680x4320, "4 spp") at FULL size, float for float against the oracle on all host cores."""
+    s = c2.parseSceneFromFile(os.path.join(SCENES, scene_file))
+    s.setFrameSize(w, h)
+    s.setDof(False)
+    cam = s.beginFrame()
+    opts = s.renderOpts(taps=taps, count_rays=1)
+    gpu_ctx.uploadScene(s.desc)
+    gpu = gpu_ctx.renderFrame(cam, opts)
+    got = gpu_ctx.rayStats()
+    st = {}
+    ref = orc.render_frame(s.desc, cam, opts, 0, st)
+    md, nbad, nne = maxdiff(gpu, ref)
+    print("%s %dx%d x%d: max|d|=%.3g, !=: %d of %d floats" % (scene_file, w, h, taps, md, nne, gpu.size))
+    assert md <= TOL and nbad == 0
+    assert got == (st["primary"], st["shadow"])
+    if rays:
+        assert got[0] == rays
+
+
 def test_planes_only_scenes(gpu_ctx, tmp_path, scenes_dir):
     """Scenes made of Plane nodes only run the kernel instances that decide a plane's miss from the
     un-normalised ray (plane_points_away): scaled / mirrored / translated / bounded planes, lights
