@@ -31,7 +31,7 @@ all: $(LIBNAME) oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so
 $(BUILD):
 	mkdir -p $(BUILD)
 
-$(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
+$(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_device.h $(CSRC)/x87.h include/c2rt.h | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$* -c $< -o $@
 
 $(BUILD)/c2rt_api.o: $(CSRC)/c2rt_api.cpp $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)

@@ -61,7 +61,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for rel in ("chess2rt_amd/csrc/c2rt_kernels.hip", "chess2rt_amd/csrc/c2rt_device.h", "include/c2rt.h", "Makefile"):
+    for rel in ("chess2rt_amd/csrc/c2rt_kernels.hip", "chess2rt_amd/csrc/c2rt_device.h", "chess2rt_amd/csrc/x87.h", "include/c2rt.h", "Makefile"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     h.update(os.environ.get("C2RT_LIB_VARIANT", "").encode())

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "c2rt_device.h"
+#include "x87.h"
 
 namespace c2rt {
 namespace {
@@ -126,14 +127,18 @@ struct Hit {          /* IntersectionData — rt/intersectable.d:6-33 (dNdx/dNdy
     bool axis_n;      /* n is an exact signed unit axis (plane, cube): normalize(n) == n */
 };
 
-/* Sphere.intersect's u,v — rt/geometry.d:116-118 */
+/* Sphere.intersect's u,v — rt/geometry.d:118-120.  `PI` is an 80-bit real there: the two expressions
+ * are evaluated with the x87's 64-bit significand and rounded to double on assignment; x87.h
+ * reproduces that with integer arithmetic (a NaN / infinite operand takes the plain double
+ * expression, whose result is the same NaN). */
 DEV void finish_uv(Hit &h)
 {
     if (h.uv_pending) {
         constexpr double PI = 3.14159265358979323846;
         const double angle = c2_atan2(h.v, h.u);
-        h.u = (PI + angle) / (2 * PI);
-        h.v = 1.0 - (PI / 2 + c2_asin(h.w)) / PI;
+        const double as = c2_asin(h.w);
+        h.u = fabs(angle) <= 4.0 ? x87_sphere_u(angle) : (PI + angle) / (2 * PI);
+        h.v = fabs(as) <= 2.0 ? x87_sphere_v(as) : 1.0 - (PI / 2 + as) / PI;
         h.uv_pending = false;
     }
 }

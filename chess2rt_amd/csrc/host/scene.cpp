@@ -76,7 +76,14 @@ Vector mul(const Vector &v, const Matrix &m)
                   v.x * m.c[0][1] + v.y * m.c[1][1] + v.z * m.c[2][1],
                   v.x * m.c[0][2] + v.y * m.c[1][2] + v.z * m.c[2][2]);
 }
-double radians(double deg) { return deg * 0x1.1df46a2529d39p-6; /* cast(double)(PI / 180) */ }
+/* gfm radians!double: `return x * (PI / 180);` — std.math.PI is an 80-bit `real`, so the constant is
+ * folded in extended precision, x is promoted, the product is formed on the x87 (64-bit significand)
+ * and rounded to double once on return.  x86-64 `long double` is that format. */
+double radians(double deg)
+{
+    static_assert(sizeof(long double) >= 10 && __LDBL_MANT_DIG__ == 64, "x87 extended precision expected on the host");
+    return (double)((long double)deg * (3.141592653589793238462643383279502884L / 180.0L));
+}
 
 static Vector operator+(const Vector &a, const Vector &b) { return Vector(a.x + b.x, a.y + b.y, a.z + b.z); }
 static Vector operator-(const Vector &a, const Vector &b) { return Vector(a.x - b.x, a.y - b.y, a.z - b.z); }

@@ -180,8 +180,13 @@ static M3 m_rotate_y(double a) { return m_rotate_axis(2, 0, a); }
 static M3 m_rotate_z(double a) { return m_rotate_axis(0, 1, a); }
 
 #define ORC_PI 3.14159265358979323846
-/* cast(double)(PI / 180) with PI an 80-bit real: nearest double of pi/180 */
-static inline double radians_(double x) { return x * 0x1.1df46a2529d39p-6; }
+/* D's std.math.PI is an 80-bit `real` (x87 extended on x86-64, which is what `long double` is here):
+ * expressions that mix it with doubles are evaluated in extended precision and rounded to double
+ * once, on assignment. */
+#define ORC_PIL 3.141592653589793238462643383279502884L
+_Static_assert(__LDBL_MANT_DIG__ == 64, "x87 extended precision expected for D's `real`");
+/* gfm radians!double: `return x * (PI / 180);` — constant folded in real, product in real, one rounding */
+static inline double radians_(double x) { return (double)((long double)x * (ORC_PIL / 180.0L)); }
 
 /* ===================================================================== */
 /* rt/imported_types.d                                                    */
@@ -432,10 +437,12 @@ static int sphere_intersect(Scene *s, int32_t g, Ray ray, ID *info)
     /* atan2, asin, cos, sin + their argument arithmetic (dNdx is computed by the reference although
      * nothing on this path reads it) */
     OPS(dlibm, 4); OPS(dadd, 8); OPS(ddiv, 3);
+    /* `PI` is a `real`: the doubles (D's atan2 / asin of doubles return doubles) are promoted, each
+     * operation rounds to the x87's 64-bit significand and the assignment rounds to double */
     double angle = atan2(info->p.z - center.z, info->p.x - center.x);
-    info->u = (ORC_PI + angle) / (2 * ORC_PI);
-    info->v = 1.0 - (ORC_PI / 2 + asin((info->p.y - center.y) / R)) / ORC_PI;
-    info->dNdx = v3(cos(angle + ORC_PI / 2), 0, sin(angle + ORC_PI / 2));
+    info->u = (double)((ORC_PIL + (long double)angle) / (2 * ORC_PIL));
+    info->v = (double)(1.0L - (ORC_PIL / 2 + (long double)asin((info->p.y - center.y) / R)) / ORC_PIL);
+    info->dNdx = v3((double)cosl((long double)angle + ORC_PIL / 2), 0, (double)sinl((long double)angle + ORC_PIL / 2));
     info->dNdy = vcross(info->dNdx, info->normal);
     info->g = g;
     return 1;

@@ -52,3 +52,17 @@ def test_plain_build_reports_that_it_does_not_count():
     L.orc_op_counts_take.restype = C.c_int
     oc = orc.OpCounts()
     assert L.orc_op_counts_take(C.byref(oc)) == 0 and oc.dadd == 0
+
+
+def test_x87_emulation_matches_the_compilers_long_double(tmp_path):
+    """chess2rt_amd/csrc/x87.h — the integer emulation the device uses for Sphere.intersect's u, v
+    (`PI` is an 80-bit real in the reference, rt/geometry.d:119-120) — against this host's own x87
+    `long double` arithmetic: special values, every binade with tie patterns, 4 M random operands."""
+    import subprocess
+
+    from golden_configs import ROOT
+
+    exe = str(tmp_path / "x87_check")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "x87_check.c"), "-lm", "-o", exe])
+    p = subprocess.run([exe, "1000000"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "mismatches 0" in p.stdout, p.stdout + p.stderr
