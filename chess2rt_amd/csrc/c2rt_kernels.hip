@@ -55,10 +55,13 @@ __device__ __noinline__ double c2_cos(double a) { return cos(a); }
 #ifndef C2RT_OCC_DEEP
 #define C2RT_OCC_DEEP 2
 #endif
-template <int LEVELS, bool DOF, bool MLC>
+template <int LEVELS, int DOF, bool MLC>
 constexpr int occ_of()
 {
-    return LEVELS == 0 ? 4 : (LEVELS == 1 ? ((DOF || MLC) ? 3 : C2RT_OCC_U1) : (LEVELS == 2 ? 2 : C2RT_OCC_DEEP));
+#ifndef C2RT_OCC_U0
+#define C2RT_OCC_U0 4
+#endif
+    return LEVELS == 0 ? (DOF ? 4 : C2RT_OCC_U0) : (LEVELS == 1 ? ((DOF || MLC) ? 3 : C2RT_OCC_U1) : (LEVELS == 2 ? 2 : C2RT_OCC_DEEP));
 }
 #define C2RT_OCC_OF(L, D, M) __attribute__((amdgpu_waves_per_eu(occ_of<L, D, M>(), occ_of<L, D, M>())))
 #ifndef C2RT_XCD_SWIZZLE
@@ -1046,7 +1049,7 @@ DEV void lens_sincos2pi(double u, double &sn, double &cs)
     if (q == 1 || q == 2) cs = -cs;
 }
 
-template <bool DOF>
+template <int DOF>
 DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &rng, D3 &orig, D3 &dir)
 {
     const c2rt_camera_frame &cam = P.cam;
@@ -1060,7 +1063,7 @@ DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &
         const D3 raw0 = dir;
         dir = normalized(raw0);
         const D3 rightDir = ld3(cam.right_dir);
-        if (offset != 0) orig = orig + rightDir * (offset > 0 ? +cam.stereo_separation : -cam.stereo_separation);
+        if (DOF == 2 && offset != 0) orig = orig + rightDir * (offset > 0 ? +cam.stereo_separation : -cam.stereo_separation);
         if (!cam.dof) { dir = raw0; return; }
         const double cosTheta = dot(dir, ld3(cam.front_dir));
         const double M = cam.focal_plane_dist / cosTheta;
@@ -1074,7 +1077,7 @@ DEV void screen_ray(const RenderParams &P, double x, double y, int offset, Rng &
         dx *= cam.disc_multiplier;
         dy *= cam.disc_multiplier;
         orig = pos + rightDir * dx + ld3(cam.up_dir) * dy;
-        if (offset != 0) orig = orig + rightDir * (offset > 0 ? +cam.stereo_separation : -cam.stereo_separation);
+        if (DOF == 2 && offset != 0) orig = orig + rightDir * (offset > 0 ? +cam.stereo_separation : -cam.stereo_separation);
         dir = T - orig; /* un-normalised */
     }
 }
@@ -1180,7 +1183,7 @@ DEV F3 combine_stereo(F3 l, F3 r)
 }
 
 /* renderSample — rt/renderer.d:254-313 */
-template <int LEVELS, bool DOF, bool MLC, bool PO>
+template <int LEVELS, int DOF, bool MLC, bool PO>
 DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, int dx, int dy, uint64_t pixel, uint32_t tap,
                      Counters &cnt, c2rt_trace_result *probe)
 {
@@ -1194,7 +1197,9 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, i
          * as ONE loop around ONE trace call site (five inlined copies of the tracer made
          * this instance five times the size of the others): lens samples x eyes, in the
          * reference's order, with the random draws in its order. */
-        const bool stereo = P.cam.stereo_separation != 0;
+        /* DOF = 1: depth of field on a mono camera (what zaphod.sdl asks for): one eye, no offset, no
+         * anaglyph merge — all of it compile-time; DOF = 2: a stereo camera, with or without depth of field */
+        const bool stereo = DOF == 2 && P.cam.stereo_separation != 0;
         const bool dof = P.cam.dof != 0;
         const uint32_t ns = dof ? P.cam.num_samples : 1u;
         const int eyes = stereo ? 2 : 1;
@@ -1209,7 +1214,7 @@ DEV F3 render_sample(const RenderParams &P, const Ctx &cx, double x, double y, i
                     sx = x + jx * dx;
                     sy = y + jy * dy;
                 }
-                screen_ray<true>(P, sx, sy, stereo ? (e == 0 ? -1 : +1) : 0, rng, o, d);
+                screen_ray<DOF>(P, sx, sy, stereo ? (e == 0 ? -1 : +1) : 0, rng, o, d);
                 const F3 c = raytrace<LEVELS, MLC, PO>(P, cx, o, d, cnt, e == 0 ? probe : nullptr);
                 sample = e == 0 ? c : combine_stereo(sample, c);
             }
@@ -1230,7 +1235,7 @@ __constant__ double k_aa_y[5] = {0.0, 0.3, 0.0, 0.6, 0.6};
  * reference's order and the pixel is written once (12 B of HBM traffic per
  * pixel).  One workgroup = one wavefront = one 8x8 tile.
  */
-template <int LEVELS, bool DOF, bool MLC, bool PO>
+template <int LEVELS, int DOF, bool MLC, bool PO>
 DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
 {
     extern __shared__ __align__(16) char lds_all[];
@@ -1390,7 +1395,7 @@ DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
 /* One tile per workgroup; in retry mode (RenderParams::retry_mode: the full-capacity relaunch of
  * the nested-CSG instances) a fixed grid walks the list of tiles whose hit stacks overflowed.
  * Either way the tile code is inlined once. */
-template <int LEVELS, bool DOF, bool MLC, bool PO>
+template <int LEVELS, int DOF, bool MLC, bool PO>
 DEV void render_body(const RenderParams &P, KArgs K)
 {
     if constexpr (LEVELS >= 2) {
@@ -1410,7 +1415,7 @@ DEV void render_body(const RenderParams &P, KArgs K)
     }
 }
 
-template <int LEVELS, bool DOF, bool MLC>
+template <int LEVELS, int DOF, bool MLC>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, DOF, MLC) render_kernel(const RenderParams P)
 {
     render_body<LEVELS, DOF, MLC, false>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr());
@@ -1418,22 +1423,22 @@ __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, DOF, MLC) r
 
 /* The depth-of-field / stereo instance carries the lens sampling state on top of
  * the tracer's and has its own register budget (C2RT_OCC_DOF). */
-template <int LEVELS, bool MLC>
-__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, true, MLC) render_kernel_dof(const RenderParams P)
+template <int LEVELS, bool MLC, int MODE>
+__global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, MODE, MLC) render_kernel_dof(const RenderParams P)
 {
-    render_body<LEVELS, true, MLC, false>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr());
+    render_body<LEVELS, MODE, MLC, false>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 /* Scenes made of axis planes only (RenderParams::planes_only — lecture4.sdl, zaphod.sdl): the
  * instances in which a plane's miss is decided before the ray is normalised (plane_points_away). */
-template <bool DOF>
+template <int DOF>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(0, DOF, false) render_kernel_planes(const RenderParams P)
 {
     render_body<0, DOF, false, true>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr()); /* at most one light (launch_render_level); planes have no boxes, hence no culling masks */
 }
 
 /* renderPixel — rt/renderer.d:46-57: one lane, one sample, full trace result */
-template <int LEVELS, bool DOF>
+template <int LEVELS, int DOF>
 __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
 {
     extern __shared__ __align__(16) char lds[];
@@ -1526,23 +1531,32 @@ int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, vo
     const dim3 grid(p.retry_mode ? 2048u : p.blocks_x * tiles_y_pad), block(kBlockThreads);
     const size_t lds = (size_t)p.csg_cap * kCsgLdsPerEntry * kWavesPerBlock;
 #if C2RT_UNIT == 0
+    const bool stereo = p.cam.stereo_separation != 0;
     if (p.planes_only && p.n_lights <= 1) { /* (planes + several lights: the general instances below) */
-        if (dof_or_stereo)
-            hipLaunchKernelGGL((render_kernel_planes<true>), grid, block, lds, s, p);
+        if (dof_or_stereo && stereo)
+            hipLaunchKernelGGL((render_kernel_planes<2>), grid, block, lds, s, p);
+        else if (dof_or_stereo)
+            hipLaunchKernelGGL((render_kernel_planes<1>), grid, block, lds, s, p);
         else
-            hipLaunchKernelGGL((render_kernel_planes<false>), grid, block, lds, s, p);
+            hipLaunchKernelGGL((render_kernel_planes<0>), grid, block, lds, s, p);
         return (int)hipGetLastError();
     }
 #endif
+#if C2RT_UNIT != 0
+    const bool stereo = p.cam.stereo_separation != 0;
+#endif
     if (dof_or_stereo) {
-        if (p.n_lights > 1)
-            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, true>), grid, block, lds, s, p);
+        /* stereo cameras are rare: one instance (any number of lights) */
+        if (stereo)
+            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, true, 2>), grid, block, lds, s, p);
+        else if (p.n_lights > 1)
+            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, true, 1>), grid, block, lds, s, p);
         else
-            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, false>), grid, block, lds, s, p);
+            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, false, 1>), grid, block, lds, s, p);
     } else if (p.n_lights > 1)
-        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, false, true>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, 0, true>), grid, block, lds, s, p);
     else
-        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, false, false>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, 0, false>), grid, block, lds, s, p);
     return (int)hipGetLastError();
 }
 
@@ -1564,7 +1578,7 @@ int launch_render(const RenderParams &p, const KernelVariant &v, void *stream)
 int launch_probe(const RenderParams &p, const KernelVariant &, void *stream)
 {
     const size_t lds = (size_t)p.csg_cap * kCsgLdsPerEntry;
-    hipLaunchKernelGGL((probe_kernel<C2RT_MAX_CSG_DEPTH, true>), dim3(1), dim3(kWave), lds,
+    hipLaunchKernelGGL((probe_kernel<C2RT_MAX_CSG_DEPTH, 2>), dim3(1), dim3(kWave), lds,
                        static_cast<hipStream_t>(stream), p);
     return (int)hipGetLastError();
 }
