@@ -51,7 +51,15 @@ oracle/libc2rt_oracle.so: oracle/c2rt_oracle.c oracle/c2rt_oracle.h include/c2rt
 oracle/libc2rt_oracle_count.so: oracle/c2rt_oracle.c oracle/c2rt_oracle.h include/c2rt.h
 	$(CC) -O2 -std=gnu11 -fPIC -shared $(FPFLAGS) -Wall -DORC_COUNT_OPS -o $@ oracle/c2rt_oracle.c -lm -lpthread
 
+# the compiler's own per-kernel register / scratch / occupancy figures (committed as profiles/rNN_resource_usage.txt:
+# rocprofv3's VGPR_Count column is in allocation granules and does not show them)
+resource-usage: | $(BUILD)
+	@for u in $(UNITS); do \
+	  $(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$$u -Rpass-analysis=kernel-resource-usage \
+	    -c $(CSRC)/c2rt_kernels.hip -o $(BUILD)/ru_u$$u.o 2>&1 | grep -E "remark:" | sed -e 's/.*remark: [^ ]* *//' -e 's/ \[-Rpass-analysis=kernel-resource-usage\]//' ; \
+	done
+
 clean:
 	rm -rf build build_* chess2rt_amd/libc2rt*.so oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so
 
-.PHONY: all clean
+.PHONY: all clean resource-usage
