@@ -61,9 +61,14 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for rel in ("chess2rt_amd/csrc/c2rt_kernels.hip", "chess2rt_amd/csrc/c2rt_device.h", "chess2rt_amd/csrc/x87.h", "include/c2rt.h", "Makefile"):
+    for rel in ("chess2rt_amd/csrc/c2rt_kernels.hip", "chess2rt_amd/csrc/c2rt_device.h", "chess2rt_amd/csrc/x87.h", "include/c2rt.h"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
+    # the flag definitions of the Makefile (not its targets or comments)
+    with open(os.path.join(ROOT, "Makefile")) as f:
+        for line in f:
+            if line.split(":=")[0].strip() in ("FPFLAGS", "HIPFLAGS", "KERNELFLAGS", "ARCH") or line.startswith("              -W"):
+                h.update(line.encode())
     h.update(os.environ.get("C2RT_LIB_VARIANT", "").encode())
     return h.hexdigest()[:16]
 

@@ -12,6 +12,6 @@ tag,w=sys.argv[1:3]
 d=json.load(open('gpurun_out/profiles_%s/%s_%s_summary.json'%(tag,tag,w)))
 c=d['pmc_per_launch_avg']; k=d['derived']
 print('%-20s kernel %.3f ms  VGPR %s scratch %s LDS %s | VALU busy %.3f lane util %.3f VALU/wave %.0f | fetch %.1f MB write %.1f MB' % (
-  w, d['avg_duration_us_timed']/1e3, d['VGPR_Count'], d['Scratch_Size'], d['LDS_Block_Size'], k.get('valu_active_over_busy',0), k.get('lane_utilisation',0), k.get('valu_insts_per_wave',0), k.get('fetch_bytes',0)/1e6, k.get('write_bytes',0)/1e6))
+  w, d['avg_duration_us_timed']/1e3, d['VGPR_Count'], d['Scratch_Size'], d['LDS_Block_Size'], k.get('valu_busy_fraction',0), k.get('lane_utilisation',0), k.get('valu_insts_per_wave',0), k.get('fetch_bytes',0)/1e6, k.get('write_bytes',0)/1e6))
 PY
 done
