@@ -201,6 +201,12 @@ class Context:
         self._check(self._lib.c2rt_get_ray_stats(self._h, C.byref(s)))
         return int(s.primary_rays), int(s.shadow_rays)
 
+    def csgTruncations(self):
+        """CsgOp child hit lists that reached C2RT_MAX_CSG_HITS during the last counted frame."""
+        n = C.c_uint64()
+        self._check(self._lib.c2rt_get_csg_truncations(self._h, C.byref(n)))
+        return int(n.value)
+
     def renderPixel(self, cam, opts, x, y):
         r = TraceResult()
         self._check(self._lib.c2rt_render_pixel(self._h, C.byref(cam), C.byref(opts), int(x), int(y), C.byref(r)))

@@ -65,7 +65,7 @@ struct c2rt_ctx {
 
     float *frame = nullptr;        /* staging frame for host-output renders */
     size_t frame_floats = 0;
-    unsigned long long *counters = nullptr; /* [2] */
+    unsigned long long *counters = nullptr; /* [3]: RenderParams::ray_counters */
     c2rt_trace_result *probe = nullptr;
     uint8_t *srgb_lut = nullptr;   /* [4097] */
     uint32_t *retry_list = nullptr; /* RenderParams::retry_list: [0] count, then tile (block) indices */
@@ -480,7 +480,7 @@ int render_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render
     p.out = out_dev;
     ctx->counters_valid = false;
     if (opts->count_rays) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 2 * sizeof(unsigned long long), stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 3 * sizeof(unsigned long long), stream));
         p.ray_counters = ctx->counters;
     }
     if (p.local_rows == 0) return C2RT_OK;
@@ -535,7 +535,7 @@ int c2rt_init(int device, c2rt_ctx **out)
     for (int i = 0; i < kMaxChunks; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chunk_done[i], hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counters), 2 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counters), 3 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->probe), sizeof(c2rt_trace_result)));
     uint8_t lut[4097];
     build_srgb_lut(lut);
@@ -940,7 +940,7 @@ static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2r
     p.out = ctx->frame;
     ctx->counters_valid = false;
     if (opts->count_rays) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
         p.ray_counters = ctx->counters;
     }
     const uint32_t rows = p.local_rows;
@@ -1041,7 +1041,7 @@ static int render_to_host_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, con
         if ((st = ensure_staging(c, px * 3 + (out_rgb32 ? px : 0))) != C2RT_OK) { st = fail(ctx, st, "slot %u: %s", d, c->err.c_str()); break; }
         p.out = c->frame;
         if (opts->count_rays) {
-            if (hipMemsetAsync(c->counters, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) { st = fail(ctx, C2RT_ERR_HIP, "counter reset"); break; }
+            if (hipMemsetAsync(c->counters, 0, 3 * sizeof(unsigned long long), c->stream) != hipSuccess) { st = fail(ctx, C2RT_ERR_HIP, "counter reset"); break; }
             p.ray_counters = c->counters;
         }
         int e = launch_frame(c, p, variant, c->stream);
@@ -1111,7 +1111,7 @@ static int render_device_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, cons
         hipStream_t s = d == 0 ? stream : c->stream;
         if (d != 0) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_ready, 0));
         if (opts->count_rays) {
-            HIP_TRY(ctx, hipMemsetAsync(c->counters, 0, 2 * sizeof(unsigned long long), s));
+            HIP_TRY(ctx, hipMemsetAsync(c->counters, 0, 3 * sizeof(unsigned long long), s));
             p.ray_counters = c->counters;
         }
         if (p.local_rows) {
@@ -1221,6 +1221,25 @@ int c2rt_get_ray_stats(c2rt_ctx *ctx, c2rt_ray_stats *out)
         HIP_TRY(ctx, hipMemcpy(h, c->counters, sizeof h, hipMemcpyDeviceToHost));
         out->primary_rays += h[0];
         out->shadow_rays += h[1];
+    }
+    if (!ctx->peers.empty()) HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return C2RT_OK;
+}
+
+int c2rt_get_csg_truncations(c2rt_ctx *ctx, uint64_t *out)
+{
+    if (!ctx || !out) return C2RT_ERR_INVALID_ARG;
+    if (!ctx->counters_valid) return fail(ctx, C2RT_ERR_INVALID_ARG, "last render did not count rays");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->counters_stream));
+    unsigned long long h = 0;
+    HIP_TRY(ctx, hipMemcpy(&h, ctx->counters + 2, sizeof h, hipMemcpyDeviceToHost));
+    *out = h;
+    for (c2rt_ctx *c : ctx->peers) {
+        HIP_TRY(ctx, hipSetDevice(c->device));
+        HIP_TRY(ctx, hipStreamSynchronize(c->stream));
+        HIP_TRY(ctx, hipMemcpy(&h, c->counters + 2, sizeof h, hipMemcpyDeviceToHost));
+        *out += h;
     }
     if (!ctx->peers.empty()) HIP_TRY(ctx, hipSetDevice(ctx->device));
     return C2RT_OK;

@@ -199,7 +199,7 @@ struct RenderParams {
     uint32_t retry_mode, retry_max;
     uint32_t *retry_list;
     float *out;                    /* local_rows * width * 3 floats */
-    unsigned long long *ray_counters; /* [2] primary, shadow (nullable) */
+    unsigned long long *ray_counters; /* [3] primary rays, shadow rays, CSG hit lists that reached the cap (nullable) */
     /* pixel probe */
     int32_t probe_x, probe_y;
     c2rt_trace_result *probe_out;

@@ -175,6 +175,14 @@ struct Ctx {
      * rendered again by the full-capacity launch (RenderParams::retry_list).  Written through const
      * references on purpose: everything here is inlined into the kernel and it lives in a register. */
     mutable bool overflow;
+    /* Where a child's hit list reaches C2RT_MAX_CSG_HITS — the reference's findAllIntersections
+     * (`while (true)`, rt/geometry.d:271-290) would have gone on, this build stops: build-defined
+     * behaviour — the lane bumps this counter (c2rt_get_csg_truncations), so that nobody has to take
+     * the cap's harmlessness on trust.  Null (at compile time) in the production instances: only the
+     * instances launched when rays are being counted carry it (render_tile's CNT) — measured in the
+     * headline kernel, which sits exactly at its 128-VGPR budget, a flag carried to the end of the tile
+     * cost 3 % and an atomic on the spot 8 %. */
+    unsigned long long *trunc_counter;
     uint32_t block;   /* the tile this wave renders (blockIdx.x, or an entry of the retry list) */
     uint32_t primary_mask; /* bit n clear: no primary ray of this tile can reach node n (wave-uniform) */
     uint32_t shadow_mask0; /* same for the tile's shadow rays towards light 0 (further lights: shadow_cull_mask) */
@@ -432,6 +440,7 @@ __device__ __forceinline__ bool csg_intersect(const Ctx &cx, const DevGeom *G, c
             ++k;
         }
         if (replay) break; /* `t` is the re-derived winner (data = current, rt/geometry.d:326) */
+        if (k == kMaxCsgHits && cx.trunc_counter) atomicAdd(cx.trunc_counter, 1ull);
         if (side == 0) nL = k;
         n += k;
         /* exact shortcuts (GeomFlags): nothing can switch the operator on */
@@ -516,6 +525,7 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
             ++k;
         }
         if (side == 0) nL = k; else nR = k;
+        if (k == kMaxCsgHits && cx.trunc_counter) atomicAdd(cx.trunc_counter, 1ull);
         n += k;
         /* exact shortcuts (GeomFlags): nothing can switch the operator on */
         if (k == 0 && (flags & (side ? kCsgShortB : kCsgShortA))) return false;
@@ -1235,7 +1245,7 @@ __constant__ double k_aa_y[5] = {0.0, 0.3, 0.0, 0.6, 0.6};
  * reference's order and the pixel is written once (12 B of HBM traffic per
  * pixel).  One workgroup = one wavefront = one 8x8 tile.
  */
-template <int LEVELS, int DOF, bool MLC, bool PO>
+template <int LEVELS, int DOF, bool MLC, bool PO, bool CNT>
 DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
 {
     extern __shared__ __align__(16) char lds_all[];
@@ -1334,6 +1344,7 @@ DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
     cx.lane = lane;
     cx.csg_cap = (int)P.csg_cap;
     cx.overflow = false;
+    cx.trunc_counter = CNT ? P.ray_counters + 2 : nullptr;
     cx.block = b;
     cx.primary_mask = pmask;
     cx.shadow_mask0 = smask0;
@@ -1386,7 +1397,10 @@ DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
     px[1] = accum.g;
     px[2] = accum.b;
 
-    if (P.ray_counters) {
+    /* CNT: the instances launched when rays are being counted (opts->count_rays).  The production
+     * instances (CNT = false) never read `cnt` nor the truncation counter: the compiler drops the
+     * per-lane counters and the whole bookkeeping from them. */
+    if constexpr (CNT) {
         atomicAdd(P.ray_counters + 0, (unsigned long long)cnt.primary);
         atomicAdd(P.ray_counters + 1, (unsigned long long)cnt.shadow);
     }
@@ -1395,7 +1409,7 @@ DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
 /* One tile per workgroup; in retry mode (RenderParams::retry_mode: the full-capacity relaunch of
  * the nested-CSG instances) a fixed grid walks the list of tiles whose hit stacks overflowed.
  * Either way the tile code is inlined once. */
-template <int LEVELS, int DOF, bool MLC, bool PO>
+template <int LEVELS, int DOF, bool MLC, bool PO, bool CNT>
 DEV void render_body(const RenderParams &P, KArgs K)
 {
     if constexpr (LEVELS >= 2) {
@@ -1407,34 +1421,34 @@ DEV void render_body(const RenderParams &P, KArgs K)
                 if (i >= (listed < P.retry_max ? listed : P.retry_max)) break;
                 b = P.retry_list[1 + i];
             }
-            render_tile<LEVELS, DOF, MLC, PO>(P, K, b);
+            render_tile<LEVELS, DOF, MLC, PO, CNT>(P, K, b);
             i += gridDim.x;
         } while (P.retry_mode);
     } else {
-        render_tile<LEVELS, DOF, MLC, PO>(P, K, blockIdx.x);
+        render_tile<LEVELS, DOF, MLC, PO, CNT>(P, K, blockIdx.x);
     }
 }
 
-template <int LEVELS, int DOF, bool MLC>
+template <int LEVELS, int DOF, bool MLC, bool CNT>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, DOF, MLC) render_kernel(const RenderParams P)
 {
-    render_body<LEVELS, DOF, MLC, false>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr());
+    render_body<LEVELS, DOF, MLC, false, CNT>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 /* The depth-of-field / stereo instance carries the lens sampling state on top of
  * the tracer's and has its own register budget (C2RT_OCC_DOF). */
-template <int LEVELS, bool MLC, int MODE>
+template <int LEVELS, bool MLC, int MODE, bool CNT>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(LEVELS, MODE, MLC) render_kernel_dof(const RenderParams P)
 {
-    render_body<LEVELS, MODE, MLC, false>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr());
+    render_body<LEVELS, MODE, MLC, false, CNT>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 /* Scenes made of axis planes only (RenderParams::planes_only — lecture4.sdl, zaphod.sdl): the
  * instances in which a plane's miss is decided before the ray is normalised (plane_points_away). */
-template <int DOF>
+template <int DOF, bool CNT>
 __global__ void __launch_bounds__(kBlockThreads) C2RT_OCC_OF(0, DOF, false) render_kernel_planes(const RenderParams P)
 {
-    render_body<0, DOF, false, true>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr()); /* at most one light (launch_render_level); planes have no boxes, hence no culling masks */
+    render_body<0, DOF, false, true, CNT>(P, (KArgs)__builtin_amdgcn_kernarg_segment_ptr()); /* at most one light (launch_render_level); planes have no boxes, hence no culling masks */
 }
 
 /* renderPixel — rt/renderer.d:46-57: one lane, one sample, full trace result */
@@ -1452,6 +1466,7 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.lane = 0;
     cx.csg_cap = (int)P.csg_cap;
     cx.overflow = false;
+    cx.trunc_counter = nullptr;
     cx.block = 0;
     cx.primary_mask = 0xFFFFFFFFu;
     cx.shadow_mask0 = 0xFFFFFFFFu;
@@ -1530,33 +1545,32 @@ int launch_render_level<C2RT_UNIT>(const RenderParams &p, bool dof_or_stereo, vo
     /* retry mode: a fixed grid walks the overflow list (render_body) */
     const dim3 grid(p.retry_mode ? 2048u : p.blocks_x * tiles_y_pad), block(kBlockThreads);
     const size_t lds = (size_t)p.csg_cap * kCsgLdsPerEntry * kWavesPerBlock;
-#if C2RT_UNIT == 0
     const bool stereo = p.cam.stereo_separation != 0;
-    if (p.planes_only && p.n_lights <= 1) { /* (planes + several lights: the general instances below) */
-        if (dof_or_stereo && stereo)
-            hipLaunchKernelGGL((render_kernel_planes<2>), grid, block, lds, s, p);
-        else if (dof_or_stereo)
-            hipLaunchKernelGGL((render_kernel_planes<1>), grid, block, lds, s, p);
-        else
-            hipLaunchKernelGGL((render_kernel_planes<0>), grid, block, lds, s, p);
+    const bool multi = p.n_lights > 1;
+#define C2RT_LAUNCH(KERNEL, ...)                                                                        \
+    do {                                                                                                \
+        if (p.ray_counters) hipLaunchKernelGGL((KERNEL<__VA_ARGS__, true>), grid, block, lds, s, p);    \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, false>), grid, block, lds, s, p);                  \
+    } while (0)
+#if C2RT_UNIT == 0
+    if (p.planes_only && !multi) { /* (planes + several lights: the general instances below) */
+        if (dof_or_stereo && stereo) C2RT_LAUNCH(render_kernel_planes, 2);
+        else if (dof_or_stereo) C2RT_LAUNCH(render_kernel_planes, 1);
+        else C2RT_LAUNCH(render_kernel_planes, 0);
         return (int)hipGetLastError();
     }
 #endif
-#if C2RT_UNIT != 0
-    const bool stereo = p.cam.stereo_separation != 0;
-#endif
     if (dof_or_stereo) {
         /* stereo cameras are rare: one instance (any number of lights) */
-        if (stereo)
-            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, true, 2>), grid, block, lds, s, p);
-        else if (p.n_lights > 1)
-            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, true, 1>), grid, block, lds, s, p);
-        else
-            hipLaunchKernelGGL((render_kernel_dof<C2RT_UNIT, false, 1>), grid, block, lds, s, p);
-    } else if (p.n_lights > 1)
-        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, 0, true>), grid, block, lds, s, p);
-    else
-        hipLaunchKernelGGL((render_kernel<C2RT_UNIT, 0, false>), grid, block, lds, s, p);
+        if (stereo) C2RT_LAUNCH(render_kernel_dof, C2RT_UNIT, true, 2);
+        else if (multi) C2RT_LAUNCH(render_kernel_dof, C2RT_UNIT, true, 1);
+        else C2RT_LAUNCH(render_kernel_dof, C2RT_UNIT, false, 1);
+    } else if (multi) {
+        C2RT_LAUNCH(render_kernel, C2RT_UNIT, 0, true);
+    } else {
+        C2RT_LAUNCH(render_kernel, C2RT_UNIT, 0, false);
+    }
+#undef C2RT_LAUNCH
     return (int)hipGetLastError();
 }
 

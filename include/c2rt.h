@@ -290,6 +290,15 @@ int c2rt_render_frame_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam,
  * (synchronises the stream of that call). */
 int c2rt_get_ray_stats(c2rt_ctx *ctx, c2rt_ray_stats *out);
 
+/* CsgOp child hit lists that reached C2RT_MAX_CSG_HITS during the last render call made with
+ * opts->count_rays = 1 (events, over primary and shadow rays; tiles redone by the hit-stack retry launch
+ * count twice).  The reference's findAllIntersections loops `while (true)`
+ * (rt/geometry.d:271-290) and does not terminate when the 1e-6 step is absorbed or a hit is NaN; this
+ * build stops after C2RT_MAX_CSG_HITS hits per child (a primitive yields at most 2).  0 means the cap
+ * did not take part in the frame; > 0 flags build-defined results (pathological coordinates, or a
+ * nested child with more than 8 boundary crossings along one ray). */
+int c2rt_get_csg_truncations(c2rt_ctx *ctx, uint64_t *out);
+
 /* Pixel probe: mirrors `renderPixel` (rt/renderer.d:46-57): one sample at
  * integer (x, y), no AA, returns the colour and the trace result. */
 int c2rt_render_pixel(c2rt_ctx *ctx, const c2rt_camera_frame *cam,

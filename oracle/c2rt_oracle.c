@@ -350,14 +350,26 @@ static inline Ray ray_project(Ray r, int a, int b, int c)
  * concatenation holds at most 16 — and the storage is the caller's stack: same contents, same
  * order, no allocator (2 KiB mallocs are above glibc's tcache limit and serialise the worker
  * threads on the arena lock, which made the multi-core baseline an allocator benchmark). */
-#define IDA_CAP (2 * C2RT_MAX_CSG_HITS)
+#define ORC_MAX_HIT_CAP 64                 /* orc_set_csg_hit_cap: how far the cap can be lifted for checking */
+#define IDA_CAP (2 * ORC_MAX_HIT_CAP)
 typedef struct { ID storage[IDA_CAP]; size_t n; } IDArray;
 
 static void ida_push(IDArray *a, const ID *v)
 {
-    if (a->n >= IDA_CAP) abort(); /* unreachable: 8 + 8 */
+    if (a->n >= IDA_CAP) abort(); /* unreachable: cap + cap */
     a->storage[a->n++] = *v;
 }
+
+/* The build-defined cap on findAllIntersections (C2RT_MAX_CSG_HITS = 8 per child, the device's cap).
+ * Tests lift it to 64 to show that it takes no part in a frame (same frame, zero truncations), and
+ * count how often a list reached it. */
+static unsigned g_csg_hit_cap = C2RT_MAX_CSG_HITS;
+static atomic_ullong g_csg_truncations;
+void orc_set_csg_hit_cap(unsigned cap)
+{
+    g_csg_hit_cap = cap < 1 ? 1 : (cap > ORC_MAX_HIT_CAP ? ORC_MAX_HIT_CAP : cap);
+}
+unsigned long long orc_take_csg_truncations(void) { return atomic_exchange(&g_csg_truncations, 0); }
 
 /* sort (shell sort) — util/array.d:95-111; compare = opCmp on dist,
  * rt/intersectable.d:27-32.  The foreach index is taken by ref and rewound
@@ -537,7 +549,9 @@ static void csg_find_all(Scene *s, int32_t geom, Ray ray, IDArray *l)
      * step is absorbed (huge coordinates) or the hit is NaN; the build caps
      * the list at C2RT_MAX_CSG_HITS per child (include/c2rt.h), on the device
      * and here alike.  A sane primitive yields at most 2 hits. */
-    for (size_t steps = 0; steps < C2RT_MAX_CSG_HITS; ++steps) {
+    const size_t cap = g_csg_hit_cap;
+    size_t steps = 0;
+    for (; steps < cap; ++steps) {
         ID temp = id_init();
         temp.dist = 1e99;
         if (!geom_intersect(s, geom, ray, &temp)) break;
@@ -547,6 +561,7 @@ static void csg_find_all(Scene *s, int32_t geom, Ray ray, IDArray *l)
         ray.orig = vadd(temp.p, vmul(ray.dir, 1e-6));
         ida_push(l, &temp);
     }
+    if (steps == cap) atomic_fetch_add(&g_csg_truncations, 1); /* the list reached the cap */
 }
 
 /* CsgOp.intersect — rt/geometry.d:292-332 */

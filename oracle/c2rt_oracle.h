@@ -108,6 +108,12 @@ double orc_rng_uniform(uint64_t seed, uint64_t pixel, uint32_t tap,
  * libm-free so that the device produces the same bits. */
 void orc_lens_sincos2pi(double u, double *sn, double *cs);
 
+/* findAllIntersections' build-defined cap (default C2RT_MAX_CSG_HITS = 8 hits per CsgOp child, clamped to
+ * 1..64) and the number of child hit lists that reached it since the last take.  Tests render with the cap
+ * at 64 to show it takes no part in a frame. */
+void orc_set_csg_hit_cap(unsigned cap);
+unsigned long long orc_take_csg_truncations(void);
+
 /* Algorithmic floating-point operation counts of the render path as the reference's source
  * executes it; only the library built with -DORC_COUNT_OPS
  * (oracle/libc2rt_oracle_count.so) tallies.  orc_op_counts_take copies the totals accumulated by

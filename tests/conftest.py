@@ -29,8 +29,26 @@ def scenes_dir():
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    import numpy as np
+
     import chess2rt_amd as c2
 
-    ctx = c2.Context(0)  # raises without a GPU: there is no CPU fallback
+    class CheckedContext(c2.Context):
+        """Frames with opts.count_rays = 1 come from the counting kernel instances, frames without from
+        the production instances (same source, the bookkeeping compiled out).  Tests ask for counted
+        frames; every such request also renders the production frame and insists on the same bits, so
+        that what is compared with the oracle is what a caller gets."""
+
+        def renderFrame(self, cam, opts, stop_flag=None):
+            if not opts.count_rays:
+                return super().renderFrame(cam, opts, stop_flag)
+            plain_opts = type(opts).from_buffer_copy(opts)
+            plain_opts.count_rays = 0
+            plain = super().renderFrame(cam, plain_opts, stop_flag)
+            counted = super().renderFrame(cam, opts, stop_flag)
+            assert np.array_equal(plain.view(np.uint32), counted.view(np.uint32)), "production and counting instances differ"
+            return counted
+
+    ctx = CheckedContext(0)  # raises without a GPU: there is no CPU fallback
     yield ctx
     ctx.close()

@@ -70,6 +70,10 @@ def lib():
         L.orc_shell_sort_hits.restype = None
         L.orc_color_to_rgb32.argtypes = [C.POINTER(C.c_float)]
         L.orc_color_to_rgb32.restype = C.c_uint32
+        L.orc_set_csg_hit_cap.argtypes = [C.c_uint]
+        L.orc_set_csg_hit_cap.restype = None
+        L.orc_take_csg_truncations.argtypes = []
+        L.orc_take_csg_truncations.restype = C.c_ulonglong
         L.orc_rng_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_rng_uniform.restype = C.c_double
         _lib = L

@@ -492,19 +492,29 @@ def test_pathological_scenes_terminate_and_match(gpu_ctx, tmp_path):
             Shaders { Lambert "l" { } }
             Nodes { Node "a" { geometry "i"; shader "l" }; Node "b" { geometry "s"; shader "l"; scale 0 0 0 }; Node "f" { geometry "p"; shader "l" } } }''', True),
     }
+    truncated = {}
     for name, (text, compare) in cases.items():
         scene = _load_text(tmp_path, text, name + ".sdl")
         scene.setFrameSize(64, 48)
         scene.setAA(False)
         cam = scene.beginFrame()
-        opts = scene.renderOpts()
+        opts = scene.renderOpts(count_rays=1)
         gpu_ctx.uploadScene(scene.desc)
         a = gpu_ctx.renderFrame(cam, opts)          # must return (bounded loops)
+        truncated[name] = gpu_ctx.csgTruncations()
         assert a.shape == (48, 64, 3)
         if compare:
             ref = orc.render_frame(scene.desc, cam, opts, 1)
             assert np.array_equal(np.isnan(a), np.isnan(ref)), name
             assert maxdiff(a, ref)[0] <= TOL, name
+    # the cap on findAllIntersections is reported where it bites (the absorbed 1e-6 step: the hit list of
+    # every ray that meets the object fills up) and nowhere else
+    assert truncated["absorbed_eps"] > 0, truncated
+    for name in sorted(CONFIGS):
+        scene, cam, opts = load_config(name, count_rays=1)
+        gpu_ctx.uploadScene(scene.desc)
+        gpu_ctx.renderFrame(cam, opts)
+        assert gpu_ctx.csgTruncations() == 0, name
 
 
 def test_rgb32_frame_and_strips(gpu_ctx):

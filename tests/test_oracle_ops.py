@@ -66,3 +66,33 @@ def test_x87_emulation_matches_the_compilers_long_double(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "x87_check.c"), "-lm", "-o", exe])
     p = subprocess.run([exe, "1000000"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "mismatches 0" in p.stdout, p.stdout + p.stderr
+
+
+def test_the_csg_hit_cap_takes_no_part_in_ordinary_frames(tmp_path):
+    """findAllIntersections is capped at C2RT_MAX_CSG_HITS = 8 hits per CsgOp child (the reference loops
+    `while (true)`).  With the cap lifted to 64 the oracle renders the same frames — golden CSG configs and
+    40 random CSG scenes up to depth 4 — and no hit list ever reaches even the cap of 8."""
+    import shutil
+
+    from scene_fuzz import random_scene_sdl
+
+    L = orc.lib()
+    shutil.copy(os.path.join(SCENES, "floor.bmp"), tmp_path / "floor.bmp")
+    cases = [load_config(n) for n in ("csg_stress_320x240_t1", "csg_corner_256x192_t1", "lecture5_333x217_t4")]
+    for seed in range(40):
+        path = tmp_path / ("f%d.sdl" % seed)
+        path.write_text(random_scene_sdl(seed, max_depth=4))
+        sc = c2.parseSceneFromFile(str(path))
+        cases.append((sc, sc.beginFrame(), sc.renderOpts()))
+    try:
+        for scene, cam, opts in cases:
+            L.orc_take_csg_truncations()
+            a = orc.render_frame(scene.desc, cam, opts, 4)
+            assert L.orc_take_csg_truncations() == 0
+            L.orc_set_csg_hit_cap(64)
+            b = orc.render_frame(scene.desc, cam, opts, 4)
+            assert L.orc_take_csg_truncations() == 0
+            L.orc_set_csg_hit_cap(8)
+            assert np.array_equal(a, b, equal_nan=True)
+    finally:
+        L.orc_set_csg_hit_cap(8)
