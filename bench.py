@@ -400,7 +400,8 @@ def phase_probe(torch, dist, pipe, world, dev, n=3):
         dist.barrier()
         torch.cuda.synchronize(dev)
 
-    acc = [0.0, 0.0, 0.0]
+    acc = [0.0, 0.0, 0.0, 0.0]
+    host = None
     for _ in range(n):
         sync()
         t0 = time.perf_counter()
@@ -420,11 +421,21 @@ def phase_probe(torch, dist, pipe, world, dev, n=3):
             pipe._deinterleave(0, pipe.stream)
         sync()
         t3 = time.perf_counter()
+        if pipe.rank == 0 and pipe.frame is not None:
+            # the assembled frame to pinned host memory (what a host-side consumer of the whole frame pays)
+            if host is None:
+                host = torch.empty(pipe.frame.shape, dtype=pipe.frame.dtype, pin_memory=True)
+            host.copy_(pipe.frame, non_blocking=True)
+        sync()
+        t4 = time.perf_counter()
         acc[0] += t1 - t0
         acc[1] += t2 - t1
         acc[2] += t3 - t2
+        acc[3] += t4 - t3
     return {"render_ms": acc[0] / n * 1e3, "exchange_ms": acc[1] / n * 1e3, "deinterleave_ms": acc[2] / n * 1e3,
-            "note": "serial frame with a barrier between phases (host clock incl. ~2 barriers of latency per phase), mean of %d" % n}
+            "frame_d2h_ms": acc[3] / n * 1e3,
+            "note": "serial frame with a barrier between phases (host clock incl. ~2 barriers of latency per phase), mean of %d; "
+                    "frame_d2h = rank 0's assembled frame to pinned host memory" % n}
 
 
 def count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev):

@@ -213,6 +213,25 @@ def test_dof_with_counter_rng_matches_oracle(gpu_ctx):
     a = gpu_ctx.renderFrame(cam, opts)
     ref = orc.render_frame(scene.desc, cam, opts, 0)
     assert maxdiff(a, ref)[0] <= TOL
+    # every camera mode through every kernel family: mono / stereo x depth of field on / off, on a
+    # planes-only scene, a depth-1 CSG scene with one light and a depth-4 CSG scene with several lights
+    for name in ("zaphod_215x143_dof25", "lecture5_333x217_t4", "csg_stress_320x240_t1"):
+        scene, cam, opts = load_config(name, count_rays=1, seed=3)
+        scene_cam = cam
+        gpu_ctx.uploadScene(scene.desc)
+        for dof, sep in ((1, 0.0), (1, 0.7), (0, 0.7)):
+            scene_cam.dof = dof
+            scene_cam.num_samples = 6
+            scene_cam.focal_plane_dist = 180.0
+            scene_cam.disc_multiplier = 10.0 / 4.0
+            scene_cam.stereo_separation = sep
+            a = gpu_ctx.renderFrame(scene_cam, opts)
+            rays = gpu_ctx.rayStats()
+            st = {}
+            ref = orc.render_frame(scene.desc, scene_cam, opts, 0, st)
+            md, nbad, nne = maxdiff(a, ref)
+            assert md <= TOL and nbad == 0, (name, dof, sep, md)
+            assert rays == (st["primary"], st["shadow"]), (name, dof, sep)
 
 
 def test_error_behaviour(scenes_dir):
