@@ -21,8 +21,9 @@ with open(os.path.join(src, "trace", "trace_kernel_trace.csv")) as f:
 # then a fixed 2048-workgroup grid over the tiles that overflowed it (usually none).  The frame launch
 # is the one with the larger grid; the retry launches are reported beside it.
 main_grid = max(int(r["Grid_Size_X"]) for r in tr_all)
-tr = [r for r in tr_all if int(r["Grid_Size_X"]) == main_grid]
-retry = [r for r in tr_all if int(r["Grid_Size_X"]) != main_grid]
+timed_name = [r for r in tr_all if int(r["Grid_Size_X"]) == main_grid][-1]["Kernel_Name"]  # not the ray-counting instance
+tr = [r for r in tr_all if int(r["Grid_Size_X"]) == main_grid and r["Kernel_Name"] == timed_name]
+retry = [r for r in tr_all if int(r["Grid_Size_X"]) != main_grid and r["Kernel_Name"] == timed_name]
 durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
 summ["kernel"] = tr[0]["Kernel_Name"]
 summ["launches"] = len(durs)
@@ -33,8 +34,10 @@ if retry:
     rd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in retry][-20:]
     summ["retry_launches"] = len(retry)
     summ["retry_avg_duration_us_timed"] = statistics.mean(rd) / 1e3
+# metadata of the TIMED launches (the first launch of a run is the ray-counting instance, another kernel)
+summ["kernel"] = tr[-1]["Kernel_Name"]
 for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X"):
-    summ[k] = tr[0][k]
+    summ[k] = tr[-1][k]
 
 counters = defaultdict(list)
 pmc_dur = {}
@@ -44,7 +47,7 @@ for sub in sorted(os.listdir(src)):
         continue
     with open(p) as f:
         for r in csv.DictReader(f):
-            if KERNEL in r["Kernel_Name"] and int(r["Grid_Size"]) == main_grid:
+            if r["Kernel_Name"] == summ["kernel"] and int(r["Grid_Size"]) == main_grid:
                 counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 pmc_dur.setdefault(sub, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 summ["pmc_per_launch_avg"] = {k: statistics.mean(v[-20:]) for k, v in counters.items()}
