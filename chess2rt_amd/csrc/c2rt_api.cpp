@@ -69,6 +69,7 @@ struct c2rt_ctx {
     c2rt_trace_result *probe = nullptr;
     uint8_t *srgb_lut = nullptr;   /* [4097] */
     uint32_t *retry_list = nullptr; /* RenderParams::retry_list: [0] count, then tile (block) indices */
+    uint32_t *tile_stats = nullptr; /* diagnostics (c2rt_debug_set_tile_stats): caller-owned device buffer */
     size_t retry_words = 0;
     bool counters_valid = false;
     hipStream_t counters_stream = nullptr;
@@ -309,6 +310,7 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
     p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
     p.blocks_x = (p.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     p.seed = o->seed;
+    p.tile_stats = ctx->tile_stats;
     p.row_group_start = 0;
     p.planes_only = ctx->planes_only;
     p.ground_node = ctx->ground_node;
@@ -583,6 +585,14 @@ int c2rt_init_multi(int device_count_or_0, const int *device_ids, c2rt_ctx **out
 }
 
 int c2rt_device_count(const c2rt_ctx *ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
+
+/* Diagnostics hook, not part of include/c2rt.h: with a library built with -DC2RT_TILE_STATS=1 the frame
+ * kernel writes {wave cycles, class bits} per tile (tiles_x * tiles_y pairs of uint32) to this device
+ * buffer; the product build ignores it.  scripts/tile_stats.py. */
+void c2rt_debug_set_tile_stats(c2rt_ctx *ctx, uint32_t *dev_buffer)
+{
+    if (ctx) ctx->tile_stats = dev_buffer;
+}
 
 uint64_t c2rt_scene_generation(const c2rt_ctx *ctx) { return ctx && ctx->has_scene ? ctx->scene_gen : 0; }
 

@@ -64,6 +64,9 @@ constexpr int occ_of()
     return LEVELS == 0 ? (DOF ? 4 : C2RT_OCC_U0) : (LEVELS == 1 ? ((DOF || MLC) ? 3 : C2RT_OCC_U1) : (LEVELS == 2 ? 2 : C2RT_OCC_DEEP));
 }
 #define C2RT_OCC_OF(L, D, M) __attribute__((amdgpu_waves_per_eu(occ_of<L, D, M>(), occ_of<L, D, M>())))
+#ifndef C2RT_TILE_STATS
+#define C2RT_TILE_STATS 0 /* diagnostics: per-tile wave cycles + class (RenderParams::tile_stats) */
+#endif
 #ifndef C2RT_XCD_SWIZZLE
 #define C2RT_XCD_SWIZZLE 1
 #endif
@@ -1270,6 +1273,9 @@ DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
 #endif
     if (trow >= P.tiles_y) return;
     const uint32_t tcol = bcol * kWavesPerBlock + wave;
+#if C2RT_TILE_STATS
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+#endif
 
     /* Which nodes can this tile's primary rays reach, and which can occlude its
      * shadow rays towards the first light?  Lane n tests node n's rectangle and a
@@ -1379,6 +1385,15 @@ DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
         accum = s == 0 ? c : accum + c;
     }
     if (ntaps > 1) accum = accum / (float)ntaps; /* `accum / 5`: Color / float */
+#if C2RT_TILE_STATS
+    if (P.tile_stats && lane == (int)__builtin_ctzll(__ballot(true))) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - stamp0;
+        const uint32_t tile = trow * P.tiles_x + tcol;
+        P.tile_stats[2 * tile] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+        /* bit 0: primary rays reach the ground only, bit 1: and so do the shadow rays; bits 8..: primary mask */
+        P.tile_stats[2 * tile + 1] = (primary_ground ? 1u : 0u) | (ground_only ? 2u : 0u) | (pmask << 8);
+    }
+#endif
 
     if constexpr (LEVELS >= 2) {
         /* some lane's nested hit lists outgrew the stack: nothing of this tile is kept; the

@@ -1,0 +1,44 @@
+"""Where a frame's wave-cycles go, by tile class (diagnostics build):
+    make VARIANT=tilestats EXTRA_KERNEL_FLAGS=-DC2RT_TILE_STATS=1
+    C2RT_LIB_VARIANT=tilestats python scripts/tile_stats.py [workload]
+Every wave stamps the shader clock at the start and end of its tile (s_memtime; with 4 waves per SIMD a
+wave's lifetime includes the time it waits for its turn, so shares are shares of resident time)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import chess2rt_amd as c2
+from chess2rt_amd import _abi
+from bench import SCENES, WORKLOADS
+
+name = sys.argv[1] if len(sys.argv) > 1 else "lecture5_4k_aa5"
+scene_file, w, h, taps, dof = WORKLOADS[name]
+ctx = c2.Context(0)
+s = c2.parseSceneFromFile(os.path.join(SCENES, scene_file)); s.setFrameSize(w, h); s.setDof(dof)
+cam = s.beginFrame(); opts = s.renderOpts(taps=taps)
+ctx.uploadScene(s.desc)
+tx, ty = (w + 7) // 8, (h + 7) // 8
+stats = torch.zeros((ty * tx, 2), dtype=torch.int32, device="cuda:0")
+lib = _abi.load_library()
+lib.c2rt_debug_set_tile_stats.argtypes = [C.c_void_p, C.c_void_p]; lib.c2rt_debug_set_tile_stats.restype = None
+lib.c2rt_debug_set_tile_stats(ctx.handle, C.c_void_p(stats.data_ptr()))
+out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda:0")
+for _ in range(3):
+    ctx.renderFrameDevice(cam, opts, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+a = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+cyc, cls = a[:, 0], a[:, 1]
+if not cyc.any():
+    raise SystemExit("no stamps: the loaded library was not built with -DC2RT_TILE_STATS=1")
+nn = s.desc.contents.n_nodes
+pm = (cls >> 8) & ((1 << min(nn, 24)) - 1)
+kind = np.where(cls & 2, "ground only (primary + shadow)", np.where(cls & 1, "ground primary, objects may shadow", "objects in view"))
+total = cyc.sum()
+print("%s: %d tiles, mean %.0f cycles per tile-wave" % (name, len(cyc), cyc.mean()))
+for k in ("ground only (primary + shadow)", "ground primary, objects may shadow", "objects in view"):
+    m = kind == k
+    if m.any():
+        print("  %-36s %5.1f %% of tiles  %5.1f %% of wave-cycles  mean %7.0f cycles" % (k, 100 * m.mean(), 100 * cyc[m].sum() / total, cyc[m].mean()))
+for n in range(min(nn, 24)):
+    m = ((pm >> n) & 1) == 1
+    print("  node %2d in the primary mask: %5.1f %% of tiles  %5.1f %% of wave-cycles  mean %7.0f cycles" % (n, 100 * m.mean(), 100 * cyc[m].sum() / total, cyc[m].mean() if m.any() else 0))
