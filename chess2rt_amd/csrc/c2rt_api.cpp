@@ -277,7 +277,44 @@ int check_frame_args(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_ren
     return C2RT_OK;
 }
 
-void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t out[4]);
+/* Convex hull of eight 2-D points (Andrew's monotone chain) as up to kHullEdges half planes
+ * a*x + b*y + c >= 0 ((a, b) of unit length), each pushed outward by `pad`.  The central projection of a
+ * box is at most a hexagon; false (nothing written) for a degenerate hull or one with more edges. */
+bool hull_half_planes(const double pts[8][2], double pad, double out[kHullEdges][3])
+{
+    int order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    std::sort(order, order + 8, [&](int i, int j) { return pts[i][0] < pts[j][0] || (pts[i][0] == pts[j][0] && pts[i][1] < pts[j][1]); });
+    auto cross = [&](int o, int a, int b) {
+        return (pts[a][0] - pts[o][0]) * (pts[b][1] - pts[o][1]) - (pts[a][1] - pts[o][1]) * (pts[b][0] - pts[o][0]);
+    };
+    int hv[17], m = 0;
+    for (int i = 0; i < 8; ++i) { /* lower chain */
+        while (m >= 2 && cross(hv[m - 2], hv[m - 1], order[i]) <= 0) --m;
+        hv[m++] = order[i];
+    }
+    for (int i = 6, t = m + 1; i >= 0; --i) { /* upper chain */
+        while (m >= t && cross(hv[m - 2], hv[m - 1], order[i]) <= 0) --m;
+        hv[m++] = order[i];
+    }
+    --m; /* the last point repeats the first; hv[0..m) is the hull, counter-clockwise */
+    if (m < 3 || m > kHullEdges) return false;
+    double tmp[kHullEdges][3];
+    for (int e = 0; e < kHullEdges; ++e) { tmp[e][0] = tmp[e][1] = 0; tmp[e][2] = 1; }
+    for (int e = 0; e < m; ++e) {
+        const double *p0 = pts[hv[e]], *p1 = pts[hv[(e + 1) % m]];
+        double a = -(p1[1] - p0[1]), b = p1[0] - p0[0]; /* interior to the left of p0 -> p1: inward normal */
+        const double len = std::sqrt(a * a + b * b);
+        if (!(len > 0) || !std::isfinite(len)) return false;
+        a /= len; b /= len;
+        const double c = -(a * p0[0] + b * p0[1]) + pad;
+        if (!std::isfinite(c)) return false;
+        tmp[e][0] = a; tmp[e][1] = b; tmp[e][2] = c;
+    }
+    std::memcpy(out, tmp, sizeof tmp);
+    return true;
+}
+
+void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t out[4], float hull[kHullEdges][3]);
 void light_side_of(const c2rt_camera_frame *cam, const double *light, int32_t out[8]);
 
 void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *o, RenderParams &p)
@@ -323,7 +360,8 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
         for (uint32_t n = 0; n < lim; ++n)
             if (ctx->node_boxed[n]) p.n_cull = n + 1;
         for (uint32_t n = 0; n < p.n_cull; ++n) {
-            if (ctx->node_boxed[n]) cull_rect_of(cam, &ctx->node_box[(size_t)n * 24], p.cull_rect[n]);
+            for (int e = 0; e < kHullEdges; ++e) { p.cull_hull[n][e][0] = p.cull_hull[n][e][1] = 0.0f; p.cull_hull[n][e][2] = 1.0f; }
+            if (ctx->node_boxed[n]) cull_rect_of(cam, &ctx->node_box[(size_t)n * 24], p.cull_rect[n], p.cull_hull[n]);
             else { p.cull_rect[n][0] = p.cull_rect[n][1] = INT32_MIN; p.cull_rect[n][2] = p.cull_rect[n][3] = INT32_MAX; }
         }
         /* dispatch order: start at the tile rows where the boxed nodes begin (their tiles are the
@@ -349,7 +387,7 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
  * box corners through the camera (a projective map, convex on the half space in
  * front of the eye), widened by 2 pixels (the AA taps reach 0.6 px, rounding is
  * ~1e-13 px).  Any corner at or behind the eye plane => the whole frame. */
-void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t out[4])
+void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t out[4], float hull[kHullEdges][3])
 {
     const int32_t kAll[4] = {INT32_MIN, INT32_MIN, INT32_MAX, INT32_MAX};
     std::memcpy(out, kAll, sizeof kAll);
@@ -366,6 +404,7 @@ void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t o
     const double det = det3(du, dv, ul);
     if (!std::isfinite(det) || det == 0) return;
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    double pts[8][2];
     for (int k = 0; k < 8; ++k) {
         double w[3];
         for (int i = 0; i < 3; ++i) w[i] = corners[3 * k + i] - cam->pos[i];
@@ -373,6 +412,7 @@ void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t o
         if (!(l > 1e-9) || !std::isfinite(a) || !std::isfinite(b)) return; /* at / behind the eye: no culling */
         const double px = a / l * cam->frame_width, py = b / l * cam->frame_height;
         if (!std::isfinite(px) || !std::isfinite(py)) return;
+        pts[k][0] = px; pts[k][1] = py;
         xmin = std::fmin(xmin, px); xmax = std::fmax(xmax, px);
         ymin = std::fmin(ymin, py); ymax = std::fmax(ymax, py);
     }
@@ -382,6 +422,17 @@ void cull_rect_of(const c2rt_camera_frame *cam, const double *corners, int32_t o
     out[1] = (int32_t)std::floor(ymin) - 2;
     out[2] = (int32_t)std::ceil(xmax) + 3;
     out[3] = (int32_t)std::ceil(ymax) + 3;
+
+    /* the hull of the eight projected corners, one outward-padded half plane per edge.  Only for rectangles
+     * of sane size (float coefficients: |c| < 1e6 keeps the evaluation error at a tile corner below
+     * 0.25 px, and the pad is 2.5 px where the rectangle's is 2). */
+    if (!hull || xmin < -3e5 || ymin < -3e5 || xmax > 3e5 || ymax > 3e5) return;
+    double hp[kHullEdges][3];
+    if (!hull_half_planes(pts, 2.5, hp)) return;
+    for (int e = 0; e < kHullEdges; ++e)
+        if (std::fabs(hp[e][2]) > 1e6) return;
+    for (int e = 0; e < kHullEdges; ++e)
+        for (int k = 0; k < 3; ++k) hull[e][k] = (float)hp[e][k];
 }
 
 /* For one light: the integer boundary coordinates x (pixels) for which the light is

@@ -25,6 +25,7 @@ constexpr int kCsgEntries = 2 * kMaxCsgHits;
 constexpr int kTileW = C2RT_TILE_W, kTileH = 64 / C2RT_TILE_W; /* one wavefront = one 8x8 pixel tile */
 constexpr int kWave = 64;
 constexpr int kMaxCullNodes = 32;  /* nodes beyond this are always tested */
+constexpr int kHullEdges = 6;      /* a projected box is at most a hexagon */
 #ifndef C2RT_MAX_CULL_LIGHTS
 #define C2RT_MAX_CULL_LIGHTS 4
 #endif
@@ -167,6 +168,12 @@ struct RenderParams {
      * disables it (depth of field, stereo, prepass). */
     uint32_t n_cull;
     int32_t cull_rect[kMaxCullNodes][4];
+    /* The same, tighter: the convex hull of the 8 projected box corners (the silhouette of a box seen
+     * from the eye has at most 6 vertices) as up to kHullEdges half planes a*x + b*y + c >= 0 in pixel
+     * coordinates ((a, b) of unit length, pushed out by 2.5 px); a tile whose four corners all lie outside
+     * ONE of them cannot contain a sample whose ray reaches the box.  A cube 250 units away under a
+     * 90-degree lens: rectangle 27.6 % of the frame, hull 17 %.  Unused edges are (0, 0, 1). */
+    float cull_hull[kMaxCullNodes][kHullEdges][3];
     /* SHADOW rays: all hit points of a tile lie inside the tile's view pyramid; a
      * node whose box is entirely beyond one side plane of that pyramid while the
      * light is on the inner side of the same plane cannot occlude any of the
@@ -207,6 +214,8 @@ struct RenderParams {
     int32_t probe_x, probe_y;
     c2rt_trace_result *probe_out;
 };
+
+static_assert(sizeof(RenderParams) <= 4096, "the kernel-argument segment holds at most 4 KiB");
 
 /* Scene feature bits selecting the kernel instance (so that a plane-only
  * scene does not pay the registers of the CSG path). */

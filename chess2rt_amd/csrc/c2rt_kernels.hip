@@ -1290,7 +1290,24 @@ DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
             bool mine;
             int r0, r1, r2, r3;
             lane_rect(P, K, lane, mine, r0, r1, r2, r3);
-            pmask = (uint32_t)__ballot(!mine || !(r2 <= tx0 || r0 >= tx0 + kTileW || r3 <= ty0 || r1 > ty1));
+            /* the node's hull (RenderParams::cull_hull): outside one padded edge with all four tile corners.
+             * Only where some node's rectangle meets the tile at all (most tiles see the ground only). */
+            bool off_hull = false;
+            const bool rect_meets = mine && !(r2 <= tx0 || r0 >= tx0 + kTileW || r3 <= ty0 || r1 > ty1);
+            if (__ballot(rect_meets)) {
+                typedef const float __attribute__((address_space(4))) *KFlt;
+                KFlt hl = (KFlt)((const char __attribute__((address_space(4))) *)K + __builtin_offsetof(RenderParams, cull_hull)) +
+                          (mine ? lane : 0) * (kHullEdges * 3);
+                const float X0 = (float)tx0, X1 = (float)(tx0 + kTileW), Y0 = (float)ty0, Y1 = (float)(ty1 + 1);
+#pragma unroll
+                for (int e = 0; e < kHullEdges; ++e) {
+                    const float a = hl[3 * e], bb = hl[3 * e + 1], c = hl[3 * e + 2];
+                    const float ax0 = a * X0, ax1 = a * X1, by0 = bb * Y0, by1 = bb * Y1;
+                    const float worst = fmaxf(fmaxf(ax0, ax1) + fmaxf(by0, by1), -3.0e38f) + c; /* the corner deepest inside */
+                    off_hull |= worst < -0.25f; /* (0.25 px: float evaluation error at |coordinates| < 1e6) */
+                }
+            }
+            pmask = (uint32_t)__ballot(!mine || !(r2 <= tx0 || r0 >= tx0 + kTileW || r3 <= ty0 || r1 > ty1 || off_hull));
             smask0 = shadow_cull_mask(P, K, b, lane, 0);
             /* Ground-plane refinement (RenderParams::ground_node): if this tile's primary rays can only
              * reach the ground plane, all its hit points lie inside the tile's footprint on that plane
