@@ -117,7 +117,11 @@ def cpu_baseline(c2, scene_file, width, height, taps, dof, rays_per_frame, budge
     t1 = time.time() - t
     one = (st1["primary"] + st1["shadow"]) / t1 / 1e6
     # algorithmic operation count of one full frame (counting build, all cores, untimed)
-    ops, _ = oracle_lib.op_counts(scene.desc, cam, opts, cores)
+    try:
+        ops, _ = oracle_lib.op_counts(scene.desc, cam, opts, cores)
+    except Exception as e:  # noqa: BLE001 — a missing counting library must not cost the bench line
+        print("bench.py: no algorithmic op count (%s)" % e, file=sys.stderr)
+        ops = None
     value = rays_per_frame / med / 1e6
     return {
         "value": value,
@@ -587,7 +591,10 @@ def main():
     if world == 1 and rank == 0 and not args.no_boundary:
         import numpy as np
 
-        boundary = boundary_timings(np, ctx, r["cam"], r["scene"].renderOpts(taps=r["taps"]))
+        try:
+            boundary = boundary_timings(np, ctx, r["cam"], r["scene"].renderOpts(taps=r["taps"]))
+        except Exception as e:  # noqa: BLE001
+            print("bench.py: host-output timings skipped (%s)" % e, file=sys.stderr)
 
     if rank == 0:
         scene, pipe = r["scene"], r["pipe"]
@@ -676,17 +683,22 @@ def main():
             out["roofline"]["valu"] = {"achieved": slots, "peak": VALU_PEAK_TSLOTS, "unit": "T lane-slots/s", "frac": slots / VALU_PEAK_TSLOTS,
                                        "insts_per_launch": valu_insts, "source": "SQ_INSTS_VALU, profiles/traffic_%s.json" % args.workload}
         if world == 1 and not args.no_cpu_baseline:
-            base, ops = cpu_baseline(c2, r["scene_file"], r["width"], r["height"], r["taps"], r["dof"], rays_per_frame)
-            out["cpu_baseline"] = base
+            try:
+                base, ops = cpu_baseline(c2, r["scene_file"], r["width"], r["height"], r["taps"], r["dof"], rays_per_frame)
+                out["cpu_baseline"] = base
+            except Exception as e:  # noqa: BLE001 — the GPU measurement above stands on its own
+                print("bench.py: cpu_baseline leg failed (%s)" % e, file=sys.stderr)
+                ops = None
             # algorithmic fp64 operations of the frame as the reference's source executes it (instrumented
             # oracle), over the live kernel time, against the non-fused fp64 vector peak
-            tops = ops["fp64"] / (r["kernel_ms"] * 1e-3) / 1e12
-            out["roofline"]["flops"] = {
-                "achieved": tops, "peak": FP64_PEAK_TOPS, "unit": "T fp64 op/s (non-fused)", "frac": tops / FP64_PEAK_TOPS,
-                "algorithmic_fp64_ops_per_launch": ops["fp64"], "ops": ops,
-                "note": "reference op count / kernel time: the kernel skips part of that work exactly (culling masks, "
-                        "bounding rejects, sign tests, lazy u,v), so this can exceed the fraction of issue slots it fills",
-            }
+            if ops:
+                tops = ops["fp64"] / (r["kernel_ms"] * 1e-3) / 1e12
+                out["roofline"]["flops"] = {
+                    "achieved": tops, "peak": FP64_PEAK_TOPS, "unit": "T fp64 op/s (non-fused)", "frac": tops / FP64_PEAK_TOPS,
+                    "algorithmic_fp64_ops_per_launch": ops["fp64"], "ops": ops,
+                    "note": "reference op count / kernel time: the kernel skips part of that work exactly (culling masks, "
+                            "bounding rejects, sign tests, lazy u,v), so this can exceed the fraction of issue slots it fills",
+                }
         print(json.dumps(out), flush=True)
 
     if world > 1:
