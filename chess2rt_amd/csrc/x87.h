@@ -137,7 +137,9 @@ X87_FN x87_t x87_div_pi(x87_t a)
     /* r = N - q * b (fits 64 bits + a little: q <= Q) */
     uint64_t th = X87_MULHI(q, b), tl = q * b;
     uint64_t rl = nl - tl, rh = nh - th - (nl < tl);
-    while (rh != 0 || rl >= b) {
+    /* (q never overestimates: R and the dropped low word both round down; it is short by at most 3.
+     * The count is bounded anyway: a device loop must not be able to spin.) */
+    for (int it = 0; it < 8 && (rh != 0 || rl >= b); ++it) {
         const uint64_t o = rl;
         rl -= b;
         rh -= (o < b);
