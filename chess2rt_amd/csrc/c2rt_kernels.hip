@@ -871,13 +871,9 @@ struct Mat {
  * two) instead of a node -> shader -> texture chain of per-lane loads. */
 DEV void load_mat(const DevNode *nodes, int closest, Mat &m)
 {
-    m.shader_type = m.tex = 0;
+    /* (lanes without a hit keep an indeterminate record: they return the environment colour before anything
+     * reads it — thirty zeroing moves per sample otherwise) */
     m.tex_type = -1;
-    m.strength = 0;
-    m.color = mkf(0, 0, 0);
-    m.exponent = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) m.td[i] = 0;
     bool todo = closest >= 0;
     while (todo) {
         const int u = __builtin_amdgcn_readfirstlane(closest);
@@ -1119,9 +1115,11 @@ DEV F3 raytrace(const RenderParams &P, const Ctx &cx, D3 o, D3 raw, Counters &cn
     const D3 d = normalized(raw);
     Hit best;
     best.dist = 1e99;
-    best.p = best.n = mk(0, 0, 0);
-    best.u = best.v = best.w = 0;
-    best.g = -1;
+    if (probe) { /* the probe reports the record even without a hit; a frame only reads it after one */
+        best.p = best.n = mk(0, 0, 0);
+        best.u = best.v = best.w = 0;
+        best.g = -1;
+    }
     best.uv_pending = false;
     best.axis_n = false;
     int closest = -1;
