@@ -186,6 +186,9 @@ struct Ctx {
      * headline kernel, which sits exactly at its 128-VGPR budget, a flag carried to the end of the tile
      * cost 3 % and an atomic on the spot 8 %. */
     unsigned long long *trunc_counter;
+#if C2RT_TILE_STATS
+    unsigned long long *lane_stats; /* diagnostics: {active, slots} pairs — [0..1] CSG evaluations entered, [2..3] child stepping calls */
+#endif
     uint32_t block;   /* the tile this wave renders (blockIdx.x, or an entry of the retry list) */
     uint32_t primary_mask; /* bit n clear: no primary ray of this tile can reach node n (wave-uniform) */
     uint32_t shadow_mask0; /* same for the tile's shadow rays towards light 0 (further lights: shadow_cull_mask) */
@@ -506,6 +509,12 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
     const int room = cx.csg_cap - base;
     const int type = G->type, left = G->left, right = G->right, flags = G->flags;
     const D3 d = ray.d;
+#if C2RT_TILE_STATS
+    if (cx.lane_stats) {
+        const unsigned long long act = __ballot(true);
+        if (cx.lane == (int)__builtin_ctzll(act)) { atomicAdd(cx.lane_stats + 0, (unsigned long long)__builtin_popcountll(act)); atomicAdd(cx.lane_stats + 1, 64ull); }
+    }
+#endif
 
     int nL = 0, nR = 0;
     int n = 0;
@@ -518,6 +527,12 @@ __device__ __forceinline__ bool csg_intersect_leaf(const Ctx &cx, const DevGeom 
         while (k < kMaxCsgHits) {
             Hit t;
             t.dist = 1e99;
+#if C2RT_TILE_STATS
+            if (cx.lane_stats) {
+                const unsigned long long act = __ballot(true);
+                if (cx.lane == (int)__builtin_ctzll(act)) { atomicAdd(cx.lane_stats + 2, (unsigned long long)__builtin_popcountll(act)); atomicAdd(cx.lane_stats + 3, 64ull); }
+            }
+#endif
             if (!geom_intersect<0, kPoint>(cx, child, rr, t, false, 0)) break;
             t.dist += cur;
             cur = t.dist;
@@ -1366,6 +1381,9 @@ DEV void render_tile(const RenderParams &P, KArgs K, const uint32_t b)
     cx.csg_cap = (int)P.csg_cap;
     cx.overflow = false;
     cx.trunc_counter = CNT ? P.ray_counters + 2 : nullptr;
+#if C2RT_TILE_STATS
+    cx.lane_stats = P.tile_stats ? reinterpret_cast<unsigned long long *>(P.tile_stats + 2 * (size_t)P.tiles_x * P.tiles_y) : nullptr;
+#endif
     cx.block = b;
     cx.primary_mask = pmask;
     cx.shadow_mask0 = smask0;
@@ -1497,6 +1515,9 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.csg_cap = (int)P.csg_cap;
     cx.overflow = false;
     cx.trunc_counter = nullptr;
+#if C2RT_TILE_STATS
+    cx.lane_stats = nullptr;
+#endif
     cx.block = 0;
     cx.primary_mask = 0xFFFFFFFFu;
     cx.shadow_mask0 = 0xFFFFFFFFu;

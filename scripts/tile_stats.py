@@ -18,7 +18,7 @@ s = c2.parseSceneFromFile(os.path.join(SCENES, scene_file)); s.setFrameSize(w, h
 cam = s.beginFrame(); opts = s.renderOpts(taps=taps)
 ctx.uploadScene(s.desc)
 tx, ty = (w + 7) // 8, (h + 7) // 8
-stats = torch.zeros((ty * tx, 2), dtype=torch.int32, device="cuda:0")
+stats = torch.zeros((ty * tx + 4, 2), dtype=torch.int32, device="cuda:0")   # + four 64-bit lane counters at the end
 lib = _abi.load_library()
 lib.c2rt_debug_set_tile_stats.argtypes = [C.c_void_p, C.c_void_p]; lib.c2rt_debug_set_tile_stats.restype = None
 lib.c2rt_debug_set_tile_stats(ctx.handle, C.c_void_p(stats.data_ptr()))
@@ -26,7 +26,9 @@ out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda:0")
 for _ in range(3):
     ctx.renderFrameDevice(cam, opts, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
-a = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+raw = stats.cpu().numpy()
+lane = raw[ty * tx:].view(np.uint64).ravel()    # {active, slots} x {CSG evaluations entered, child stepping calls}, over the 3 frames
+a = raw[:ty * tx].astype(np.int64) & 0xFFFFFFFF
 cyc, cls = a[:, 0], a[:, 1]
 if not cyc.any():
     raise SystemExit("no stamps: the loaded library was not built with -DC2RT_TILE_STATS=1")
@@ -42,3 +44,6 @@ for k in ("ground only (primary + shadow)", "ground primary, objects may shadow"
 for n in range(min(nn, 24)):
     m = ((pm >> n) & 1) == 1
     print("  node %2d in the primary mask: %5.1f %% of tiles  %5.1f %% of wave-cycles  mean %7.0f cycles" % (n, 100 * m.mean(), 100 * cyc[m].sum() / total, cyc[m].mean() if m.any() else 0))
+if lane[1]:
+    print("  depth-1 CSG evaluations entered: %.1f of 64 lanes active on average (%.3f); child stepping calls: %.1f of 64 (%.3f)" % (
+        64.0 * lane[0] / lane[1], lane[0] / lane[1], 64.0 * lane[2] / max(lane[3], 1), lane[2] / max(lane[3], 1)))
