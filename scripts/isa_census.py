@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Static ISA census of one kernel instance: instructions by class, attributed to the source function whose
+statement each instruction was generated from (the most recent `.loc` line of a -gline-tables-only build; the
+whole trace is inlined into the kernel, so the line's enclosing function in c2rt_kernels.hip names the region).
+
+usage: isa_census.py <unit> <mangled-name-substring> [--md]
+Builds build/isa/u<unit>g.s with the Makefile's flags + -gline-tables-only (code generation is unchanged).
+"""
+import collections
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "chess2rt_amd/csrc/c2rt_kernels.hip")
+
+
+def make_flags():
+    flags = {}
+    for line in open(os.path.join(ROOT, "Makefile")):
+        m = re.match(r"^(FPFLAGS|KERNELFLAGS)\s*:=\s*(.*)$", line)
+        if m:
+            flags[m.group(1)] = m.group(2).strip()
+    return flags
+
+
+def function_spans():
+    """(first line, last line, name) of every function body in the kernel source (brace matching from a
+    line that looks like a definition at namespace scope)."""
+    lines = open(SRC).read().split("\n")
+    spans = []
+    i = 0
+    sig = re.compile(r"^(?:template\s*<[^>]*>\s*)?(?:DEV|__device__|__global__|static|inline|int|void)\b.*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;]*$")
+    while i < len(lines):
+        m = sig.match(lines[i])
+        if m and not lines[i].startswith(" "):
+            name = m.group(1)
+            # find the opening brace
+            j = i
+            depth = 0
+            opened = False
+            while j < len(lines):
+                for ch in lines[j]:
+                    if ch == "{":
+                        depth += 1
+                        opened = True
+                    elif ch == "}":
+                        depth -= 1
+                if opened and depth == 0:
+                    break
+                if not opened and lines[j].rstrip().endswith(";"):
+                    break
+                j += 1
+            if opened:
+                spans.append((i + 1, j + 1, name))
+                i = j
+        i += 1
+    return spans
+
+
+CLASSES = [
+    ("fp64 add/mul/fma", re.compile(r"^v_(add|mul|fma|fmac)_f64")),
+    ("fp64 transcendental seed (rcp/rsq/sqrt)", re.compile(r"^v_(rcp|rsq|sqrt)_f64")),
+    ("fp64 divide/sqrt scaffolding (div_scale/fmas/fixup, ldexp, cmp_class)", re.compile(r"^v_(div_scale|div_fmas|div_fixup|ldexp|frexp_\w+)_f64|^v_cmp_class_f64")),
+    ("fp64 compare", re.compile(r"^v_cmpx?_\w+_f64")),
+    ("fp64 min/max/floor/cvt", re.compile(r"^v_(max|min|floor|ceil|trunc|rndne|fract)_f64|^v_cvt_\w*f64|^v_cvt_f64")),
+    ("select (v_cndmask)", re.compile(r"^v_cndmask")),
+    ("64-bit move", re.compile(r"^v_mov_b64|^v_accvgpr")),
+    ("32-bit move", re.compile(r"^v_mov_b32")),
+    ("spill-lane traffic (v_readlane/v_writelane)", re.compile(r"^v_(readlane|writelane|readfirstlane)")),
+    ("fp32 arithmetic", re.compile(r"^v_\w+_f32|^v_pk_\w+_f32")),
+    ("integer / logic VALU", re.compile(r"^v_")),
+    ("LDS", re.compile(r"^ds_")),
+    ("global / scratch memory", re.compile(r"^(global|flat|scratch|buffer)_")),
+    ("scalar memory", re.compile(r"^s_(load|buffer_load|store)")),
+    ("branch", re.compile(r"^s_(cbranch|branch|setpc|swappc|call)")),
+    ("wait / nop", re.compile(r"^s_(waitcnt|nop|sleep)")),
+    ("SALU", re.compile(r"^s_")),
+]
+
+
+def classify(op):
+    for name, rx in CLASSES:
+        if rx.match(op):
+            return name
+    return "other"
+
+
+def main():
+    unit, pat = sys.argv[1], sys.argv[2]
+    flags = make_flags()
+    out = os.path.join(ROOT, "build", "isa", "u%sg.s" % unit)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags["FPFLAGS"].split() + \
+          ["-fhip-fp32-correctly-rounded-divide-sqrt"] + flags["KERNELFLAGS"].split() + \
+          ["-DC2RT_UNIT=%s" % unit, "-gline-tables-only", "--offload-device-only", "-S", SRC, "-o", out, "-I" + os.path.join(ROOT, "include")]
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(SRC):
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    spans = function_spans()
+
+    def region_of(fileno, line):
+        if fileno == 3:
+            return "x87.h (Sphere u,v in x87 extended precision)"
+        if fileno not in (0,):
+            return "device libm / HIP headers"
+        for a, b, name in spans:
+            if a <= line <= b:
+                return name
+        return "(file scope)"
+
+    per_region = collections.defaultdict(collections.Counter)
+    total = collections.Counter()
+    inside = False
+    cur = ("?", 0)
+    kname = None
+    for raw in open(out):
+        s = raw.strip()
+        if not inside:
+            if re.match(r"^_Z\w+:", s) and pat in s:
+                inside = True
+                kname = s.split(":")[0]
+            continue
+        if s.startswith(".Lfunc_end") or s.startswith(".section") and "rodata" in s:
+            break
+        m = re.match(r"^\.loc\s+(\d+)\s+(\d+)", s)
+        if m:
+            cur = (int(m.group(1)), int(m.group(2)))
+            continue
+        if not s or s.startswith(".") or s.startswith(";") or s.endswith(":"):
+            continue
+        op = s.split()[0]
+        c = classify(op)
+        per_region[region_of(*cur)][c] += 1
+        total[c] += 1
+    n = sum(total.values())
+    print("# Static ISA census of `%s`\n" % kname)
+    print("%d instructions.  By class:\n" % n)
+    print("| class | instructions | share |\n|---|---|---|")
+    for name, _ in CLASSES + [("other", None)]:
+        if total[name]:
+            print("| %s | %d | %.1f %% |" % (name, total[name], 100.0 * total[name] / n))
+    print("\nBy source region (function of c2rt_kernels.hip the statement belongs to), largest first; columns: all / fp64 arithmetic / "
+          "fp64 seeds / divide-sqrt scaffolding / compares / selects / moves (32+64) / spill lanes / SALU+branch+wait:\n")
+    print("| region | all | fp64 arith | seeds | scaffolding | fp64 cmp | selects | moves | spill lanes | scalar |\n|---|---|---|---|---|---|---|---|---|---|")
+    for reg, cnt in sorted(per_region.items(), key=lambda kv: -sum(kv[1].values())):
+        tot = sum(cnt.values())
+        if tot < 10:
+            continue
+        print("| %s | %d | %d | %d | %d | %d | %d | %d | %d | %d |" % (
+            reg, tot, cnt["fp64 add/mul/fma"], cnt["fp64 transcendental seed (rcp/rsq/sqrt)"],
+            cnt["fp64 divide/sqrt scaffolding (div_scale/fmas/fixup, ldexp, cmp_class)"], cnt["fp64 compare"], cnt["select (v_cndmask)"],
+            cnt["64-bit move"] + cnt["32-bit move"], cnt["spill-lane traffic (v_readlane/v_writelane)"],
+            cnt["SALU"] + cnt["branch"] + cnt["wait / nop"] + cnt["scalar memory"]))
+
+
+if __name__ == "__main__":
+    main()
