@@ -26,12 +26,12 @@ UNITS      := 0 1 2 3 4 5
 KOBJS      := $(foreach u,$(UNITS),$(BUILD)/c2rt_kernels_u$(u).o)
 HOBJS      := $(BUILD)/c2rt_api.o $(BUILD)/dsc.o $(BUILD)/scene.o $(BUILD)/host_api.o
 
-all: $(LIBNAME) oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so
+all: $(LIBNAME) oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so tests/fp64_lean_check
 
 $(BUILD):
 	mkdir -p $(BUILD)
 
-$(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_device.h $(CSRC)/x87.h include/c2rt.h | $(BUILD)
+$(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_trace.inc $(CSRC)/c2rt_device.h $(CSRC)/x87.h $(CSRC)/fp64_lean.h include/c2rt.h | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$* -c $< -o $@
 
 $(BUILD)/c2rt_api.o: $(CSRC)/c2rt_api.cpp $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
@@ -42,6 +42,10 @@ $(BUILD)/%.o: $(CSRC)/host/%.cpp $(CSRC)/host/scene.hpp $(CSRC)/host/dsc.hpp inc
 
 $(LIBNAME): $(KOBJS) $(HOBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
+
+# device check of fp64_lean.h against the compiler's own divide / sqrt expansions (tests/test_gpu_parity.py runs it)
+tests/fp64_lean_check: tests/fp64_lean_check.hip $(CSRC)/fp64_lean.h
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 $(FPFLAGS) $< -o $@
 
 # CPU oracle: plain C restatement of the reference algorithm (tests only)
 oracle/libc2rt_oracle.so: oracle/c2rt_oracle.c oracle/c2rt_oracle.h include/c2rt.h
@@ -60,6 +64,6 @@ resource-usage: | $(BUILD)
 	done
 
 clean:
-	rm -rf build build_* chess2rt_amd/libc2rt*.so oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so
+	rm -rf build build_* chess2rt_amd/libc2rt*.so oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so tests/fp64_lean_check
 
 .PHONY: all clean resource-usage

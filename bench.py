@@ -61,7 +61,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for rel in ("chess2rt_amd/csrc/c2rt_kernels.hip", "chess2rt_amd/csrc/c2rt_device.h", "chess2rt_amd/csrc/x87.h", "include/c2rt.h"):
+    for rel in ("chess2rt_amd/csrc/c2rt_kernels.hip", "chess2rt_amd/csrc/c2rt_trace.inc", "chess2rt_amd/csrc/c2rt_device.h", "chess2rt_amd/csrc/x87.h", "chess2rt_amd/csrc/fp64_lean.h", "include/c2rt.h"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     # the flag definitions of the Makefile (not its targets or comments)
@@ -452,6 +452,21 @@ def count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev):
     return int(rays[0].item()), int(rays[1].item())
 
 
+def self_launch(n):
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting %s" % (n, " ".join(cmd[1:9])), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,16 +481,24 @@ def main():
     ap.add_argument("--strip-height", type=int, default=0, help="rows per strip (multiple of 8); default 8 (gather) / 32 (p2p: one message per strip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = single-GPU rehearsal of the N>1 flow: host-staged gather, every rank on device 0")
-    ap.add_argument("--gather", default="auto", choices=["auto", "float", "rgb32"],
-                    help="N>1: what crosses xGMI — the float Image!Color strips (12 B/pixel) or their RGB32 display encoding "
-                         "(Color.toRGB32 on each rank, 4 B/pixel).  auto (default): a calibration pass times one render and one "
-                         "serial float exchange; float is kept when its exchange fits inside 0.9 x the render time (so double "
-                         "buffering hides it), otherwise the strips cross the links display-encoded")
+    ap.add_argument("--gather", default="float", choices=["float", "auto", "rgb32"],
+                    help="N>1: what crosses xGMI.  float (default): the Image!Color strips, 12 B/pixel — the reference's output "
+                         "contract, so the assembled frame on rank 0 is the frame the parity tests check.  rgb32: each rank "
+                         "display-encodes its strips first (Color.toRGB32, 4 B/pixel) and rank 0 assembles the window-blit frame — "
+                         "a narrower output, named as such in config.workload.  auto: a calibration pass times one render and one "
+                         "serial float exchange and picks rgb32 when the float exchange cannot hide behind the render")
     ap.add_argument("--exchange", default="gather", choices=["gather", "p2p"],
                     help="N>1: one RCCL gather + de-interleave pass on rank 0 (default), or one receive per remote strip "
                          "straight into its place in the frame (no gather buffer, no de-interleave pass)")
-    ap.add_argument("--check", action="store_true", help="N>1: compare the gathered frame with a single-rank render (bit-exact)")
+    ap.add_argument("--no-check", action="store_true", help="N>1: skip comparing the first assembled frame with a single-rank render of the whole frame (bit-exact)")
+    ap.add_argument("--check", action="store_true", help="(default since round 3; kept for old command lines)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one rank per GPU under torch.distributed.run as a CHILD process
+        # (before anything here has touched the GPU; a process that has must never be replaced) and relay its
+        # JSON line and exit code
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -517,9 +540,9 @@ def main():
 
     ctx = c2.Context(local_rank)
 
-    def run(workload, steps, warmup):
+    def run(workload, steps, warmup, scaling=None):
         scene_file, w0, h0, taps, dof = WORKLOADS[workload]
-        width, height = (weak_frame(w0, h0, world) if args.scaling == "weak" else (w0, h0))
+        width, height = (weak_frame(w0, h0, world) if (scaling or args.scaling) == "weak" else (w0, h0))
         scene = c2.parseSceneFromFile(os.path.join(SCENES, scene_file))
         scene.setFrameSize(width, height)
         scene.setDof(dof)
@@ -552,24 +575,47 @@ def main():
                     primary=primary, shadow=shadow, elapsed=elapsed, kernel_ms=kernel_ms, steps=steps, phases=phases,
                     calib=calib)
 
-    r = run(args.workload, args.steps, args.warmup)
-
-    if args.check and world > 1 and rank == 0:
-        # the gathered + de-interleaved frame must equal a whole-frame render bit for bit
-        pipe = r["pipe"]
-        whole = torch.empty((r["height"], r["width"], 3), dtype=torch.float32, device=dev)
-        ctx.renderFrameDevice(r["cam"], r["scene"].renderOpts(taps=r["taps"]), whole.data_ptr(), pipe.stream.cuda_stream)
-        torch.cuda.synchronize(dev)
-        if pipe.rgb32:
-            packed = torch.empty((r["height"], r["width"]), dtype=torch.int32, device=dev)
-            ctx.encodeRGB32(whole.data_ptr(), packed.data_ptr(), r["height"] * r["width"], pipe.stream.cuda_stream)
+    def check_frame(r):
+        """N>1: the frame rank 0 assembled from every rank's strips must equal rank 0's own render of the WHOLE
+        frame bit for bit; every rank learns the verdict (a failing run must end on all of them)."""
+        ok = torch.ones(1, dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        if rank == 0:
+            pipe = r["pipe"]
+            whole = torch.empty((r["height"], r["width"], 3), dtype=torch.float32, device=dev)
+            ctx.renderFrameDevice(r["cam"], r["scene"].renderOpts(taps=r["taps"]), whole.data_ptr(), pipe.stream.cuda_stream)
             torch.cuda.synchronize(dev)
-            whole = packed
-        if not torch.equal(whole, pipe.frame):
-            raise SystemExit("bench.py --check: gathered frame differs from the single-rank frame")
-        print("bench.py --check: gathered frame == single-rank frame (bit-exact)", file=sys.stderr)
+            if pipe.rgb32:
+                packed = torch.empty((r["height"], r["width"]), dtype=torch.int32, device=dev)
+                ctx.encodeRGB32(whole.data_ptr(), packed.data_ptr(), r["height"] * r["width"], pipe.stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                whole = packed
+            ok[0] = 1 if torch.equal(whole, pipe.frame) else 0
+            del whole
+        dist.broadcast(ok, 0)
+        if int(ok.item()) != 1:
+            raise SystemExit("bench.py: the frame assembled from %d ranks differs from the single-rank frame" % world)
+        return "assembled frame == rank 0's own render of the whole frame, bit for bit"
+
+    r = run(args.workload, args.steps, args.warmup)
+    frame_check = None
+    if world > 1 and not args.no_check:
+        frame_check = check_frame(r)
 
     others = {}
+    if world > 1 and not args.no_others and not (args.workload == "lecture5_8k_4spp" and args.scaling == "strong"):
+        # BASELINE config 5 itself: data/lecture5.sdl at 7680x4320 x4, ONE frame sharded over the ranks (strong scaling)
+        o = run("lecture5_8k_4spp", min(args.steps, 20), min(args.warmup, 3), scaling="strong")
+        rays = o["primary"] + o["shadow"]
+        others["lecture5_8k_4spp_strong"] = {
+            "workload": "%s %dx%d, %d tap(s), one frame over %d ranks (BASELINE configs[4])" % (o["scene_file"], o["width"], o["height"], o["taps"], world),
+            "Mray_per_s": rays * o["steps"] / o["elapsed"] / 1e6,
+            "ms_per_frame": o["elapsed"] / o["steps"] * 1e3,
+            "kernel_ms_rank0": o["kernel_ms"],
+            "rays_per_frame": rays,
+            "phases_ms": o["phases"],
+            "frame_check": check_frame(o) if not args.no_check else None,
+        }
+        del o
     if world == 1 and not args.no_others:
         for name in WORKLOADS:
             if name == args.workload:
@@ -671,6 +717,7 @@ def main():
             out["config"]["devices"] = devices
             out["config"]["phases_ms"] = r["phases"]
             out["config"]["wire_format"] = "rgb32" if pipe.rgb32 else "float"
+            out["config"]["frame_check"] = frame_check
             if r["calib"]:
                 out["config"]["wire_format_calibration"] = r["calib"]
         if boundary:

@@ -161,6 +161,7 @@ C2RT_SYMBOLS = {
     "c2rt_device_count": (C.c_int, [_VP]),
     "c2rt_scene_generation": (C.c_uint64, [_VP]),
     "c2rt_get_csg_truncations": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    "c2rt_get_exact_redos": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "c2rt_destroy": (None, [_VP]),
     "c2rt_last_error": (C.c_char_p, [_VP]),
     "c2rt_status_string": (C.c_char_p, [C.c_int]),

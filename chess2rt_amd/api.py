@@ -207,6 +207,12 @@ class Context:
         self._check(self._lib.c2rt_get_csg_truncations(self._h, C.byref(n)))
         return int(n.value)
 
+    def exactRedos(self):
+        """Tiles this context has rendered a second time through the compiler's divide / sqrt (cumulative)."""
+        n = C.c_uint64()
+        self._check(self._lib.c2rt_get_exact_redos(self._h, C.byref(n)))
+        return int(n.value)
+
     def renderPixel(self, cam, opts, x, y):
         r = TraceResult()
         self._check(self._lib.c2rt_render_pixel(self._h, C.byref(cam), C.byref(opts), int(x), int(y), C.byref(r)))

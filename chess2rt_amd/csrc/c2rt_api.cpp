@@ -65,7 +65,7 @@ struct c2rt_ctx {
 
     float *frame = nullptr;        /* staging frame for host-output renders */
     size_t frame_floats = 0;
-    unsigned long long *counters = nullptr; /* [3]: RenderParams::ray_counters */
+    unsigned long long *counters = nullptr; /* [0..2]: RenderParams::ray_counters (reset per counted frame); [3]: RenderParams::redo_counter (cumulative) */
     c2rt_trace_result *probe = nullptr;
     uint8_t *srgb_lut = nullptr;   /* [4097] */
     uint32_t *retry_list = nullptr; /* RenderParams::retry_list: [0] count, then tile (block) indices */
@@ -503,6 +503,7 @@ int launch_frame(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStre
     p.csg_cap = (uint32_t)first_cap;
     if (levels == 0) p.csg_cap = 0;
     p.retry_mode = 0;
+    p.redo_counter = ctx->counters + 3;
     if (levels < 2) return launch_render(p, v, stream);
     const size_t blocks = (size_t)p.blocks_x * ((p.tiles_y + 7u) / 8u * 8u);
     if (blocks + 1 > ctx->retry_words) {
@@ -588,7 +589,8 @@ int c2rt_init(int device, c2rt_ctx **out)
     for (int i = 0; i < kMaxChunks; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chunk_done[i], hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counters), 3 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counters), 4 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemset(ctx->counters, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->probe), sizeof(c2rt_trace_result)));
     uint8_t lut[4097];
     build_srgb_lut(lut);
@@ -1300,6 +1302,24 @@ int c2rt_get_csg_truncations(c2rt_ctx *ctx, uint64_t *out)
         HIP_TRY(ctx, hipSetDevice(c->device));
         HIP_TRY(ctx, hipStreamSynchronize(c->stream));
         HIP_TRY(ctx, hipMemcpy(&h, c->counters + 2, sizeof h, hipMemcpyDeviceToHost));
+        *out += h;
+    }
+    if (!ctx->peers.empty()) HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return C2RT_OK;
+}
+
+int c2rt_get_exact_redos(c2rt_ctx *ctx, uint64_t *out)
+{
+    if (!ctx || !out) return C2RT_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    unsigned long long h = 0;
+    HIP_TRY(ctx, hipMemcpy(&h, ctx->counters + 3, sizeof h, hipMemcpyDeviceToHost));
+    *out = h;
+    for (c2rt_ctx *c : ctx->peers) {
+        HIP_TRY(ctx, hipSetDevice(c->device));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipMemcpy(&h, c->counters + 3, sizeof h, hipMemcpyDeviceToHost));
         *out += h;
     }
     if (!ctx->peers.empty()) HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -210,6 +210,9 @@ struct RenderParams {
     uint32_t *tile_stats;
     float *out;                    /* local_rows * width * 3 floats */
     unsigned long long *ray_counters; /* [3] primary rays, shadow rays, CSG hit lists that reached the cap (nullable) */
+    /* tiles that the production instances rendered a second time through the compiler's divide / sqrt
+     * because a lane met an operand outside a lean window (c2rt_trace.inc); cumulative, never null */
+    unsigned long long *redo_counter;
     /* pixel probe */
     int32_t probe_x, probe_y;
     c2rt_trace_result *probe_out;

@@ -28,7 +28,7 @@
  * window).  Callers branch wave-uniformly (`__all`) to the compiler's expansion when a lane is outside.
  *
  * sqrt_lean / inv_len: the compiler's own rsq + Goldschmidt sequence minus the 2^-767 scale test, the two
- * ldexp and the zero / infinity select — identical bits for 2^-700 <= x < 2^700.  inv_len also returns
+ * ldexp and the zero / infinity select — identical bits for 2^-700 <= x < 2^700 (sqrt_ok accepts 2^+-240).  inv_len also returns
  * RN(1 / RN(sqrt x)), what `1.0 / sqrt(x)` yields, but seeds the reciprocal with the 0.5/sqrt(x) the
  * square root has already refined instead of a second quarter-rate v_rcp_f64 and two Newton steps.
  * Verified against the compiler's expansions on the device and against the host's IEEE operations:
@@ -51,10 +51,12 @@ LEAN_DEV bool in_window(double x)
     return t < ((uint32_t)(HI - LO) << 21);
 }
 
-/* windows in which the sequences below are the compiler's expansions bit for bit */
+/* windows in which the sequences below are the compiler's expansions bit for bit (the tracer tests ONE
+ * window, sqrt_ok's, for numerators and radicands alike: c2rt_trace.inc, Oob) */
 LEAN_DEV bool den_ok(double b) { return in_window<-120, 120>(b); }
 LEAN_DEV bool num_ok(double a) { return in_window<-900, 700>(a); }
-LEAN_DEV bool sqrt_ok(double x) { return in_window<-700, 700>(x); }
+/* (the square of den_ok's window: a length taken from such an x can be divided by) */
+LEAN_DEV bool sqrt_ok(double x) { return in_window<-240, 240>(x); }
 
 /* the refined reciprocal of the compiler's division: v_rcp_f64 + two Newton steps */
 LEAN_DEV double rcp_refined(double b)
@@ -74,7 +76,7 @@ LEAN_DEV double div_with(double a, double b, double r)
     return __builtin_fma(rem, r, q);
 }
 
-/* sqrt(x) for sqrt_ok(x); *half_inv = the refined 0.5 / sqrt(x) of the same iteration */
+/* sqrt(x) for 2^-700 <= x < 2^700; *half_inv = the refined 0.5 / sqrt(x) of the same iteration */
 LEAN_DEV double sqrt_lean(double x, double *half_inv = nullptr)
 {
     const double y = __builtin_amdgcn_rsq(x);
@@ -91,14 +93,15 @@ LEAN_DEV double sqrt_lean(double x, double *half_inv = nullptr)
     return g;
 }
 
-/* len = sqrt(x) and inv = 1.0 / len, both correctly rounded, for sqrt_ok(x) && inv_ok(len).  The reciprocal
- * starts from 2h ~ 1/sqrt(x) (relative error ~2^-51 after the square root's own refinement): one Newton step
- * brings it within the last bit, then the division's correction step (q = 1 * r; rem = 1 - len * q;
- * q + rem * r) rounds it correctly — Markstein's theorem — EXCEPT for a significand of all ones
- * (len = 2^e (2 - 2^-52): 1/len sits 2^-106 above a rounding midpoint, and the correction step started from
- * the lower neighbour lands exactly on the tie): inv_ok(len) refuses a low dword of all ones, and the
- * caller takes the compiler's division for that wave (once in 2^32 lengths). */
-LEAN_DEV bool inv_ok(double len) { return (uint32_t)__double2loint(len) != 0xFFFFFFFFu; }
+/* len = sqrt(x) and inv = 1.0 / len, both correctly rounded, for sqrt_ok(x).  The reciprocal starts from
+ * 2h ~ 1/sqrt(x) (relative error ~2^-51 after the square root's own refinement): one Newton step brings it
+ * within the last bit, then the division's correction step (q = 1 * r; rem = 1 - len * q; q + rem * r) rounds
+ * it correctly — Markstein's theorem — EXCEPT for a significand of all ones, len = 2^e (2 - 2^-52) (the
+ * double below a power of two: |p - c| on a sphere of radius 1, 2, 4, ... is one a third of the time):
+ * 1 / len = 2^-(e+1) (1 + 2^-53 + 2^-106 + ..) sits 2^-106 above a rounding midpoint, the iteration arrives
+ * at the lower neighbour 2^-(e+1) with rem = 2^-53 exactly and the correction step lands on the tie, which
+ * rounds to even: back to 2^-(e+1).  The correct result is its upper neighbour, whose low dword is 1: four
+ * 32-bit instructions patch it in. */
 LEAN_DEV void inv_len(double x, double &len, double &inv)
 {
     double h;
@@ -107,7 +110,10 @@ LEAN_DEV void inv_len(double x, double &len, double &inv)
     const double e = __builtin_fma(-len, r, 1.0);
     r = __builtin_fma(r, e, r);
     const double rem = __builtin_fma(-len, r, 1.0);
-    inv = __builtin_fma(rem, r, r);
+    r = __builtin_fma(rem, r, r);
+    const uint32_t lhi = (uint32_t)__double2hiint(len), llo = (uint32_t)__double2loint(len);
+    const bool ones = ((lhi | 0xFFF00000u) & llo) == 0xFFFFFFFFu;
+    inv = __hiloint2double(__double2hiint(r), ones ? 1 : __double2loint(r));
 }
 
 /*

@@ -299,6 +299,17 @@ int c2rt_get_ray_stats(c2rt_ctx *ctx, c2rt_ray_stats *out);
  * nested child with more than 8 boundary crossings along one ray). */
 int c2rt_get_csg_truncations(c2rt_ctx *ctx, uint64_t *out);
 
+/* How many 8x8 tiles this context has rendered TWICE since it was created (synchronises the device).
+ * The frame kernels evaluate fp64 divide / sqrt / normalise with shortened, correctly rounded sequences
+ * that are valid for operands within about 1e+-70 of the scene's scale (chess2rt_amd/csrc/fp64_lean.h);
+ * every use tests its operands, and a tile in which any lane met a zero numerator, an infinity, a NaN or
+ * an operand beyond those windows discards its result and is rendered again with the compiler's IEEE
+ * expansions — the same pixels as rounds 1-2 produced, at about twice the time for that tile.  A growing
+ * number therefore costs speed, never correctness: e.g. a camera placed exactly on the plane of a cube face
+ * (every ray's numerator for that face is 0).  Frames rendered with opts->count_rays take the IEEE path
+ * only and do not count here. */
+int c2rt_get_exact_redos(c2rt_ctx *ctx, uint64_t *out);
+
 /* Pixel probe: mirrors `renderPixel` (rt/renderer.d:46-57): one sample at
  * integer (x, y), no AA, returns the colour and the trace result. */
 int c2rt_render_pixel(c2rt_ctx *ctx, const c2rt_camera_frame *cam,

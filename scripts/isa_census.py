@@ -99,15 +99,24 @@ def main():
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     spans = function_spans()
 
+    files = {}
+    for raw in open(out):
+        m = re.match(r'^\s*\.file\s+(\d+)\s+(?:"[^"]*"\s+)?"([^"]*)"', raw)
+        if m:
+            files[int(m.group(1))] = os.path.basename(m.group(2))
+
     def region_of(fileno, line):
-        if fileno == 3:
+        name = files.get(fileno, "?")
+        if name == "x87.h":
             return "x87.h (Sphere u,v in x87 extended precision)"
-        if fileno not in (0,):
+        if name == "fp64_lean.h":
+            return "fp64_lean.h (lean divide / sqrt / reciprocal length)"
+        if name != "c2rt_kernels.hip":
             return "device libm / HIP headers"
         for a, b, name in spans:
             if a <= line <= b:
                 return name
-        return "(file scope)"
+        return "vector helpers (D3 / F3 operators, dot, sqmag)" if line < 140 else "(file scope)"
 
     per_region = collections.defaultdict(collections.Counter)
     total = collections.Counter()

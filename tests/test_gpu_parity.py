@@ -882,3 +882,81 @@ def test_headline_config_full_frame(gpu_ctx):
     print("lecture5 4K x5: max|d|=%.3g, !=: %d of %d floats" % (md, nne, gpu.size))
     assert md <= TOL and nbad == 0
     assert (primary, shadow) == (st["primary"], st["shadow"]) == (41472000, 41472000)
+
+
+def test_fp64_lean_sequences_match_the_compilers_expansions_on_the_device():
+    """chess2rt_amd/csrc/fp64_lean.h (what the production kernel instances divide, take square roots and
+    normalise with) against hipcc's own expansions of `/` and `sqrt` evaluated in the same kernel, and against
+    the host's IEEE operations on a sampled slice: 2^30 operands per routine incl. structured significands
+    (all ones, single bits, both sides of powers of two), every squared length within 64 ulp of 1, window
+    edges, zeros / subnormals / infinities / NaNs refused (tests/fp64_lean_check.hip; the long sweep is
+    scripts/fp64_lean_sweep.sh)."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fp64_lean_check")
+    out = subprocess.run([exe, "30"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    print(rep)
+    assert rep["operands_per_routine"] >= 1 << 30 and rep["host_sample"] >= 1 << 20
+    for k in ("div_window", "div_tracer_range", "sqrt_lean", "inv_len", "renormalise", "unit_len_exhaustive", "window_edges",
+              "div_by_rounded_reciprocal", "div_by_unit_len", "host_mismatches", "not_near_one"):
+        assert rep[k] == 0, (k, rep)
+    assert rep["inv_len_all_ones_significands"] > 0   # the patched tie case was exercised
+
+
+def test_tiles_outside_the_lean_windows_are_redone_through_the_exact_path(gpu_ctx, tmp_path):
+    """The production instances render a tile optimistically with the shortened divide / sqrt sequences and
+    render it AGAIN with the compiler's IEEE expansions when a lane met an operand outside their window
+    (c2rt_trace.inc).  (a) On the shipped scenes nothing is redone: the lean path is what runs and what
+    every other test compares with the oracle.  (b) A zero numerator (the eye exactly on the plane of a cube
+    face), coordinates beyond 1e+72 in a sum of squares, a NaN camera: tiles are redone (counted by
+    c2rt_get_exact_redos) and the frames still match the oracle, float for float."""
+    for name in sorted(CONFIGS):
+        scene, cam, opts = load_config(name)
+        gpu_ctx.uploadScene(scene.desc)
+        before = gpu_ctx.exactRedos()
+        gpu_ctx.renderFrame(cam, opts)
+        redone = gpu_ctx.exactRedos() - before
+        if name.startswith("csg_corner"):
+            # build-authored corner cases (Op(a, a), a Diff whose right subtree contains its left primitive): stepped
+            # origins coincide with surfaces exactly, numerators are exact zeros — a few tiles take the exact path
+            assert 0 < redone < 300, (name, redone)
+        else:
+            assert redone == 0, (name, redone)
+    cases = {
+        # cube top face at y = 1 = the eye's height: (o.y - yhi) is exactly 0 for every ray that reaches the face test
+        "eye_on_face_plane": '''Scene { Camera { pos 0 1 -5; fov 60 }
+            Lights { PointLight "k" { pos 3 10 -4; color 1 1 1; power 300 } }
+            Geometries { Cube "c" { center 0 0.5 0; side 1 }; Sphere "s" { center 0 0.5 0; R 0.6 }; CsgDiff "d" { left "c"; right "s" }; Plane "p" { y 0 } }
+            Shaders { Phong "l" { color 0.9 0.4 0.1 }; Lambert "f" { } }
+            Nodes { Node "n" { geometry "d"; shader "l" }; Node "g" { geometry "p"; shader "f" } } }''',
+        # squared distances of 1e160: far outside [2^-240, 2^240)
+        "astronomic_scale": '''Scene { Camera { pos 0 0 0; fov 50 }
+            Lights { PointLight "k" { pos 0 6e80 0; color 1 1 1; power 1e164 } }
+            Geometries { Sphere "s" { center 0 0 5e80; R 1e80 }; Cube "c" { center 2.5e80 0 6e80; side 1.5e80 } }
+            Shaders { Lambert "l" { } }
+            Nodes { Node "a" { geometry "s"; shader "l" }; Node "b" { geometry "c"; shader "l" } } }''',
+        "nan_camera": '''Scene { Camera { fov 60 }
+            Lights { PointLight "k" { pos 0 10 0; color 1 1 1; power 100 } }
+            Geometries { Sphere "s" { center 0 0 5; R 1 } }
+            Shaders { Phong "l" { } }
+            Nodes { Node "n" { geometry "s"; shader "l" } } }''',
+    }
+    for name, text in cases.items():
+        scene = _load_text(tmp_path, text, name + ".sdl")
+        scene.setFrameSize(160, 120)
+        for taps in (1, 5):
+            scene.setAA(taps == 5)
+            cam = scene.beginFrame()
+            opts = scene.renderOpts(taps=taps, count_rays=1)
+            gpu_ctx.uploadScene(scene.desc)
+            before = gpu_ctx.exactRedos()
+            gpu = gpu_ctx.renderFrame(cam, opts)   # the production instance AND the exact-only counting instance, bit-equal
+            redone = gpu_ctx.exactRedos() - before
+            ref = orc.render_frame(scene.desc, cam, opts, 0)
+            assert np.array_equal(np.isnan(gpu), np.isnan(ref)), name
+            md, nbad, nne = maxdiff(gpu, ref)
+            print("%s x%d: %d tiles redone, max|d|=%.3g, !=: %d" % (name, taps, redone, md, nne))
+            assert redone > 0, name
+            assert md <= TOL and nbad == 0, name
