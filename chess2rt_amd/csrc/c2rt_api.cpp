@@ -335,6 +335,15 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
         p.cam_du[i] = cam->up_right[i] - cam->up_left[i];
         p.cam_dv[i] = cam->down_left[i] - cam->up_left[i];
     }
+    /* lean:: divides sample coordinates by the camera's frame size through these (c2rt_trace.inc, screen_ray);
+     * a frame size that is not a sane denominator (the ABI accepts any positive double), or C2RT_EXACT=1 in
+     * the environment (A/B runs: the compiler's IEEE divide / sqrt everywhere, as in rounds 1-2), sends
+     * every tile down the exact:: path */
+    p.cam_rw = 1.0 / cam->frame_width;
+    p.cam_rh = 1.0 / cam->frame_height;
+    static const bool env_exact = [] { const char *e = std::getenv("C2RT_EXACT"); return e && e[0] == '1'; }();
+    const auto sane = [](double v) { return v >= 0x1p-100 && v < 0x1p100; };
+    p.force_exact = (env_exact || !sane(cam->frame_width) || !sane(cam->frame_height)) ? 1u : 0u;
     p.width = o->width;
     p.height = o->height;
     p.taps = o->prepass_bucket ? 1u : o->taps;

@@ -151,6 +151,8 @@ struct RenderParams {
 
     c2rt_camera_frame cam;
     double cam_du[3], cam_dv[3];   /* up_right - up_left, down_left - up_left (rt/camera.d:140-142) */
+    double cam_rw, cam_rh;         /* 1.0 / frame_width, 1.0 / frame_height, IEEE (fp64_lean.h: div_with through the rounded reciprocal) */
+    uint32_t force_exact;          /* 1: every tile through exact:: (c2rt_kernels.hip, render_one) */
 
     uint32_t width, height;        /* frame */
     uint32_t taps;

@@ -96,11 +96,12 @@ DEV void render_one(const RenderParams &P, KArgs K, const uint32_t b)
     if constexpr (CNT || !C2RT_LEAN) {
         exact::render_tile<LEVELS, DOF, MLC, PO, CNT>(P, (exact::KArgs)K, b);
     } else {
-        const bool redo = lean::render_tile<LEVELS, DOF, MLC, PO, false>(P, (lean::KArgs)K, b);
-        if (__ballot(redo)) {
+        if (!P.force_exact) { /* wave-uniform */
+            const bool redo = lean::render_tile<LEVELS, DOF, MLC, PO, false>(P, (lean::KArgs)K, b);
+            if (!__ballot(redo)) return;
             if (threadIdx.x % kWave == 0) atomicAdd(P.redo_counter, 1ull); /* c2rt_get_exact_redos */
-            exact::render_tile<LEVELS, DOF, MLC, PO, false>(P, (exact::KArgs)K, b);
         }
+        exact::render_tile<LEVELS, DOF, MLC, PO, false>(P, (exact::KArgs)K, b);
     }
 }
 
