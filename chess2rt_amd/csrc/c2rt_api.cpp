@@ -73,6 +73,10 @@ struct c2rt_ctx {
     size_t retry_words = 0;
     bool counters_valid = false;
     hipStream_t counters_stream = nullptr;
+    /* the stream of the last frame enqueued without a host sync (c2rt_render_frame_device); has_inflight
+     * is cleared by the blocking entry points */
+    hipStream_t inflight_stream = nullptr;
+    bool has_inflight = false;
 };
 
 namespace {
@@ -298,13 +302,22 @@ bool hull_half_planes(const double pts[8][2], double pad, double out[kHullEdges]
     }
     --m; /* the last point repeats the first; hv[0..m) is the hull, counter-clockwise */
     if (m < 3 || m > kHullEdges) return false;
+    /* Two projected corners that nearly coincide (the eye almost on the line of a box edge) pass the turn
+     * tests on noise-dominated cross products and would contribute an "edge" whose half plane is not a
+     * supporting line of the true hull — it could cull tiles the box covers.  Such a hull is refused (the
+     * caller keeps the rectangle, which has no such failure mode): every edge must be longer than 1e-6 of
+     * the hull's extent. */
+    double ext = 0;
+    for (int i = 0; i < m; ++i)
+        for (int j = i + 1; j < m; ++j)
+            ext = std::fmax(ext, std::fmax(std::fabs(pts[hv[i]][0] - pts[hv[j]][0]), std::fabs(pts[hv[i]][1] - pts[hv[j]][1])));
     double tmp[kHullEdges][3];
     for (int e = 0; e < kHullEdges; ++e) { tmp[e][0] = tmp[e][1] = 0; tmp[e][2] = 1; }
     for (int e = 0; e < m; ++e) {
         const double *p0 = pts[hv[e]], *p1 = pts[hv[(e + 1) % m]];
         double a = -(p1[1] - p0[1]), b = p1[0] - p0[0]; /* interior to the left of p0 -> p1: inward normal */
         const double len = std::sqrt(a * a + b * b);
-        if (!(len > 0) || !std::isfinite(len)) return false;
+        if (!(len > 1e-6 * ext) || !std::isfinite(len)) return false;
         a /= len; b /= len;
         const double c = -(a * p0[0] + b * p0[1]) + pad;
         if (!std::isfinite(c)) return false;
@@ -506,7 +519,12 @@ int launch_frame(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStre
     const int levels = ctx->csg_levels;
     /* test hook: C2RT_CSG_FIRST_CAP=<entries> shrinks the first pass's stack so that the overflow ->
      * retry path runs on ordinary scenes (tests/test_gpu_parity.py); never below 1, never above full */
-    static const int forced_cap = [] { const char *e = std::getenv("C2RT_CSG_FIRST_CAP"); return e ? std::atoi(e) : 0; }();
+    static const int forced_cap = [] {
+        const char *e = std::getenv("C2RT_CSG_FIRST_CAP");
+        const int v = e ? std::atoi(e) : 0;
+        if (v > 0) std::fprintf(stderr, "libc2rt: test hook C2RT_CSG_FIRST_CAP=%d is active (first-pass CSG hit stacks shrunk; frames are unchanged, nested-CSG scenes are slower)\n", v);
+        return v;
+    }();
     int first_cap = kCsgFirstCap(levels);
     if (forced_cap > 0 && levels >= 2) first_cap = forced_cap < kCsgFullCap(levels) ? forced_cap : kCsgFullCap(levels);
     p.csg_cap = (uint32_t)first_cap;
@@ -618,7 +636,8 @@ int c2rt_init_multi(int device_count_or_0, const int *device_ids, c2rt_ctx **out
     const int n = device_count_or_0 == 0 ? visible : device_count_or_0;
     std::vector<int> ids(n);
     for (int i = 0; i < n; ++i) {
-        ids[i] = device_ids ? device_ids[i] : i;
+        /* device_count_or_0 == 0 means "every visible device": the caller's list (which may be empty) is not read */
+        ids[i] = (device_ids && device_count_or_0 > 0) ? device_ids[i] : i;
         if (ids[i] < 0 || ids[i] >= visible) return C2RT_ERR_NO_DEVICE;
     }
     c2rt_ctx *lead = nullptr;
@@ -648,13 +667,16 @@ int c2rt_init_multi(int device_count_or_0, const int *device_ids, c2rt_ctx **out
 
 int c2rt_device_count(const c2rt_ctx *ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
 
-/* Diagnostics hook, not part of include/c2rt.h: with a library built with -DC2RT_TILE_STATS=1 the frame
- * kernel writes {wave cycles, class bits} per tile (tiles_x * tiles_y pairs of uint32) to this device
- * buffer; the product build ignores it.  scripts/tile_stats.py. */
+#if defined(C2RT_TILE_STATS) && C2RT_TILE_STATS
+/* Diagnostics hook, in the diagnostics build only (make VARIANT=tilestats EXTRA_HIPFLAGS=-DC2RT_TILE_STATS=1;
+ * the product library does not export it and include/c2rt.h does not declare it): the frame kernel writes
+ * {wave cycles, class bits} per tile (tiles_x * tiles_y pairs of uint32) to this device buffer.
+ * scripts/tile_stats.py. */
 void c2rt_debug_set_tile_stats(c2rt_ctx *ctx, uint32_t *dev_buffer)
 {
     if (ctx) ctx->tile_stats = dev_buffer;
 }
+#endif
 
 uint64_t c2rt_scene_generation(const c2rt_ctx *ctx) { return ctx && ctx->has_scene ? ctx->scene_gen : 0; }
 
@@ -1004,9 +1026,19 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
  * stop flag is polled between chunks (finer than the reference's between-pass polling).  Into
  * pageable memory: one launch, one copy — chunked copies into pageable memory are slower than one
  * (measured).  ctx->frame holds the float rows, followed by the packed rows for the RGB32 form. */
+/* the blocking entry points: nothing of an earlier stream-async frame of this context may still be in flight
+ * (it would share the retry list and the counters), and nothing is in flight when they return */
+static int drain_inflight(c2rt_ctx *ctx)
+{
+    if (ctx->has_inflight) HIP_TRY(ctx, hipStreamSynchronize(ctx->inflight_stream));
+    ctx->has_inflight = false;
+    return C2RT_OK;
+}
+
 static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_rgb,
                           uint32_t *out_rgb32, const volatile uint8_t *stop_flag)
 {
+    if (const int st = drain_inflight(ctx)) return st;
     RenderParams p;
     fill_params(ctx, cam, opts, p);
     p.out = ctx->frame;
@@ -1085,6 +1117,7 @@ constexpr uint32_t kMultiStrip = kTileH;
 static int render_to_host_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_rgb,
                                 uint32_t *out_rgb32, const volatile uint8_t *stop_flag)
 {
+    if (const int st = drain_inflight(ctx)) return st;
     const uint32_t G = 1u + (uint32_t)ctx->peers.size();
     const uint32_t sh = kMultiStrip, H = opts->height, W = opts->width;
     const uint32_t n_strips = (H + sh - 1) / sh, rem = H % sh; /* rem > 0: the last strip is partial */
@@ -1169,7 +1202,16 @@ static int render_device_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, cons
     ctx->counters_valid = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_ready, stream));
-    for (uint32_t d = 0; d < G; ++d) {
+    /* A failure half way through must not leave a peer as the current device, nor peers that were already
+     * launched still storing into `out_dev` unordered against the caller's stream: whatever happens, the lead
+     * device is current again and `stream` waits for the ev_done of every peer launched so far. */
+    uint32_t launched = 0; /* peers whose ev_done has been recorded */
+    int st = C2RT_OK;
+    const auto step = [&](hipError_t e, const char *what, uint32_t d) {
+        if (e != hipSuccess && st == C2RT_OK) st = fail(ctx, C2RT_ERR_HIP, "%s (slot %u): %s", what, d, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    for (uint32_t d = 0; d < G && st == C2RT_OK; ++d) {
         c2rt_ctx *c = d == 0 ? ctx : ctx->peers[d - 1];
         c2rt_render_opts o = *opts;
         o.strip_height = kMultiStrip;
@@ -1179,21 +1221,28 @@ static int render_device_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, cons
         fill_params(c, cam, &o, p);
         p.out = out_dev;
         p.frame_rows = 1;
-        HIP_TRY(ctx, hipSetDevice(c->device));
+        if (!step(hipSetDevice(c->device), "hipSetDevice", d)) break;
         hipStream_t s = d == 0 ? stream : c->stream;
-        if (d != 0) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_ready, 0));
+        if (d != 0 && !step(hipStreamWaitEvent(s, ctx->ev_ready, 0), "hipStreamWaitEvent", d)) break;
         if (opts->count_rays) {
-            HIP_TRY(ctx, hipMemsetAsync(c->counters, 0, 3 * sizeof(unsigned long long), s));
+            if (!step(hipMemsetAsync(c->counters, 0, 3 * sizeof(unsigned long long), s), "counter reset", d)) break;
             p.ray_counters = c->counters;
         }
         if (p.local_rows) {
             const int e = launch_frame(c, p, variant, s);
-            if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch (slot %u): %s", d, hipGetErrorString((hipError_t)e));
+            if (e != 0) { step((hipError_t)e, "render kernel launch", d); /* fall through: order what was queued */ }
         }
-        if (d != 0) HIP_TRY(ctx, hipEventRecord(c->ev_done, s));
+        if (d != 0) {
+            if (!step(hipEventRecord(c->ev_done, s), "hipEventRecord", d)) break;
+            launched = d;
+        }
     }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (c2rt_ctx *c : ctx->peers) HIP_TRY(ctx, hipStreamWaitEvent(stream, c->ev_done, 0));
+    (void)hipSetDevice(ctx->device);
+    for (uint32_t d = 1; d <= launched; ++d) {
+        const hipError_t e = hipStreamWaitEvent(stream, ctx->peers[d - 1]->ev_done, 0);
+        if (e != hipSuccess && st == C2RT_OK) st = fail(ctx, C2RT_ERR_HIP, "hipStreamWaitEvent (slot %u): %s", d, hipGetErrorString(e));
+    }
+    if (st != C2RT_OK) return st;
     if (opts->count_rays) {
         ctx->counters_valid = true;
         ctx->counters_stream = stream;
@@ -1222,9 +1271,15 @@ int c2rt_render_frame_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const 
     if (st != C2RT_OK) return st;
     if (!out_rgb_dev) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
     if ((st = check_multi_opts(ctx, opts)) != C2RT_OK) return st;
-    if (!ctx->peers.empty()) return render_device_multi(ctx, cam, opts, out_rgb_dev, static_cast<hipStream_t>(hip_stream));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return render_device(ctx, cam, opts, out_rgb_dev, static_cast<hipStream_t>(hip_stream));
+    /* one frame of a context in flight at a time across streams (include/c2rt.h): the retry list and the
+     * counters are per context, and two frames on two streams would race on them */
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (ctx->has_inflight && ctx->inflight_stream != stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->inflight_stream));
+    ctx->inflight_stream = stream;
+    ctx->has_inflight = true;
+    if (!ctx->peers.empty()) return render_device_multi(ctx, cam, opts, out_rgb_dev, stream);
+    return render_device(ctx, cam, opts, out_rgb_dev, stream);
 }
 
 int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_rgb,

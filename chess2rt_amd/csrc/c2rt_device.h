@@ -207,7 +207,7 @@ struct RenderParams {
     uint32_t csg_cap;
     uint32_t retry_mode, retry_max;
     uint32_t *retry_list;
-    /* diagnostics build only (make VARIANT=tilestats EXTRA_KERNEL_FLAGS=-DC2RT_TILE_STATS=1, scripts/tile_stats.py):
+    /* diagnostics build only (make VARIANT=tilestats EXTRA_HIPFLAGS=-DC2RT_TILE_STATS=1, scripts/tile_stats.py):
      * per tile {shader-clock cycles the wave spent on it, class bits}; never read by the product build */
     uint32_t *tile_stats;
     float *out;                    /* local_rows * width * 3 floats */

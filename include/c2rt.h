@@ -281,7 +281,13 @@ int c2rt_unpin_host_buffer(c2rt_ctx *ctx, float *out_rgb);
 
 /* Same, but the output stays in HBM: `out_rgb_dev` is a device pointer
  * (e.g. a torch tensor's data_ptr) and the kernels are enqueued on
- * `hip_stream` (a hipStream_t, NULL = default stream) without a host sync. */
+ * `hip_stream` (a hipStream_t, NULL = default stream) without a host sync.
+ * Frames of ONE context are ordered: per-frame scratch of the context (the
+ * nested-CSG retry list, the ray counters) belongs to the frame in flight, so
+ * a frame enqueued on a DIFFERENT stream than the context's previous frame
+ * first waits, on the host, for that previous stream to drain
+ * (hipStreamSynchronize) — correct, but no overlap: keep a context on one
+ * stream, and use one context per stream for frames that should overlap. */
 int c2rt_render_frame_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam,
                              const c2rt_render_opts *opts, float *out_rgb_dev,
                              void *hip_stream);

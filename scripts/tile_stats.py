@@ -1,5 +1,5 @@
 """Where a frame's wave-cycles go, by tile class (diagnostics build):
-    make VARIANT=tilestats EXTRA_KERNEL_FLAGS=-DC2RT_TILE_STATS=1
+    make VARIANT=tilestats EXTRA_HIPFLAGS=-DC2RT_TILE_STATS=1
     C2RT_LIB_VARIANT=tilestats python scripts/tile_stats.py [workload]
 Every wave stamps the shader clock at the start and end of its tile (s_memtime; with 4 waves per SIMD a
 wave's lifetime includes the time it waits for its turn, so shares are shares of resident time)."""

@@ -32,6 +32,20 @@ def test_every_declared_symbol_is_exported(header, table):
     assert sorted(table) == declared
 
 
+def test_every_exported_symbol_is_declared():
+    """The converse: the product library exports no c2rt_* entry point that the two headers do not declare
+    (diagnostics hooks live in diagnostics builds only)."""
+    import subprocess
+
+    lib_path = _abi.LIB_PATH
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-1].startswith("c2rt_")})
+    declared = set(declared_functions("c2rt.h")) | set(declared_functions("c2rt_host.h"))
+    assert exported, lib_path
+    extra = [n for n in exported if n not in declared]
+    assert not extra, "exported but declared in no header: %s" % extra
+
+
 def test_abi_version_and_status_strings():
     lib = _abi.load_library()
     assert lib.c2rt_abi_version() == _abi.ABI_VERSION

@@ -960,3 +960,79 @@ def test_tiles_outside_the_lean_windows_are_redone_through_the_exact_path(gpu_ct
             print("%s x%d: %d tiles redone, max|d|=%.3g, !=: %d" % (name, taps, redone, md, nne))
             assert redone > 0, name
             assert md <= TOL and nbad == 0, name
+
+
+def test_interactive_camera_sequence_matches_the_oracle(gpu_ctx):
+    """The GUI loop (gui/raytracer_demo.d:268-340): Camera.move / Camera.rotate (rt/camera.d:181-229) ->
+    beginFrame -> renderRT, ten frames in a row on one context, each compared with the oracle.  The path walks the
+    eye INTO the CsgDiff's box and into the globe, turns until nodes straddle the eye plane and looks straight down
+    with the light behind the eye: the per-frame culling rectangles, hulls and light half-spaces are recomputed for
+    all of those (c2rt_api.cpp: cull_rect_of, light_side_of)."""
+    scene = c2.parseSceneFromFile(os.path.join(SCENES, "lecture5.sdl"))
+    scene.setFrameSize(320, 240)
+    gpu_ctx.uploadScene(scene.desc)
+    steps = [
+        ((0, 0, 0), (0, 0, 0)),          # the file's camera
+        ((-25, 0, 0), (0, 0, 100)),      # turn towards the CSG object, walk forward
+        ((0, 0, 0), (0, 0, 120)),        # ... to just in front of / inside its bounding box
+        ((0, 0, 60), (0, 0, 0)),         # look up: floor leaves the view
+        ((90, 0, 0), (10, 0, 0)),        # quarter turn: objects straddle the eye plane
+        ((0, 0, -100), (0, 0, 0)),       # pitch clamps at -90: straight down, the light behind the eye
+        ((0, 0, 45), (0, 300, 0)),       # high above the scene
+        ((180, 0, 0), (0, 0, -50)),      # look back
+        ((-60, 30, -20), (150, -200, 80)),  # rolled camera, towards the globe
+        ((0, -30, 0), (0, 0, 60)),       # ... and closer
+    ]
+    cam = scene.beginFrame()
+    for i, (rot, mov) in enumerate(steps):
+        scene.rotateCamera(*rot)
+        cam = scene.beginFrame()         # the GUI calls beginFrame between rotate and move as part of the frame
+        scene.moveCamera(*mov)
+        cam = scene.beginFrame()
+        scene.setAA(i % 2 == 1)
+        opts = scene.renderOpts(count_rays=1)
+        gpu = gpu_ctx.renderFrame(cam, opts)
+        primary, shadow = gpu_ctx.rayStats()
+        stats = {}
+        ref = orc.render_frame(scene.desc, cam, opts, 0, stats)
+        md, nbad, nne = maxdiff(gpu, ref)
+        print("step %d pos %s yaw %.0f pitch %.0f roll %.0f: max|d|=%.3g, !=: %d" % (i, [round(v, 1) for v in scene.camera.pos], scene.camera.yaw, scene.camera.pitch, scene.camera.roll, md, nne))
+        assert md <= TOL and nbad == 0, i
+        assert (primary, shadow) == (stats["primary"], stats["shadow"]), i
+    # the eye really went inside boxes: at some step the CSG node's cull rectangle covered the frame
+    assert scene.camera.pos[1] != 165.0
+
+
+def test_frames_of_one_context_on_two_streams_are_ordered(gpu_ctx):
+    """c2rt_render_frame_device on two different streams of ONE context, back to back, for a nested-CSG scene
+    (its frames use the context's retry list): include/c2rt.h promises that the second frame first waits for the
+    first stream, so both frames are complete and equal the frames rendered alone."""
+    import torch
+
+    scene, cam_a, opts = load_config("csg_stress_320x240_t1")
+    gpu_ctx.uploadScene(scene.desc)
+    scene.rotateCamera(20, 0, -5)
+    cam_b = scene.beginFrame()
+    dev = torch.device("cuda", 0)
+    H, W = opts.height, opts.width
+    alone = []
+    for cam in (cam_a, cam_b):
+        t = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        gpu_ctx.renderFrameDevice(cam, opts, t.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        alone.append(t.clone())
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    for rep in range(5):
+        a = torch.full((H, W, 3), -1.0, dtype=torch.float32, device=dev)
+        b = torch.full((H, W, 3), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        gpu_ctx.renderFrameDevice(cam_a, opts, a.data_ptr(), s1.cuda_stream)
+        gpu_ctx.renderFrameDevice(cam_b, opts, b.data_ptr(), s2.cuda_stream)
+        gpu_ctx.renderFrameDevice(cam_a, opts, a.data_ptr(), s1.cuda_stream)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(a, alone[0]) and torch.equal(b, alone[1]), rep
+    # and a blocking host-output frame right after a stream-async one
+    gpu_ctx.renderFrameDevice(cam_b, opts, b.data_ptr(), s2.cuda_stream)
+    host = gpu_ctx.renderFrame(cam_a, opts)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(host, alone[0].cpu().numpy()) and torch.equal(b, alone[1])

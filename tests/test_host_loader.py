@@ -207,6 +207,30 @@ def test_bmp_decode_known_answers_and_oracle_agreement(golden_dir, scenes_dir):
         assert np.array_equal(a, b), f
 
 
+def test_bmp_decode_of_the_references_other_textures(golden_dir):
+    """data/texture/{heightfield (8-bpp), hf_color, wood, zar-bump, zar-texture (24-bpp), lava
+    (32-bpp)}.bmp through the host decoder (imageio/bmp.d:60-193 mirrored) and the oracle's: equal each other and
+    equal the committed SHA-256 of the decoded float frame (tests/golden/make_bmp_texture_hashes.py).  The files
+    are read where the reference keeps them; they exist in the build container only."""
+    import hashlib
+
+    fx = json.load(open(os.path.join(golden_dir, "bmp_texture_hashes.json")))["files"]
+    src = "/root/reference/data/texture"
+    if not os.path.isdir(src):
+        pytest.skip("the reference's texture files are not on this machine")
+    assert sorted(fx) == ["heightfield.bmp", "hf_color.bmp", "lava.bmp", "wood.bmp", "zar-bump.bmp", "zar-texture.bmp"]
+    assert {e["bpp"] for e in fx.values()} == {8, 24, 32}
+    for f, e in fx.items():
+        data = open(os.path.join(src, f), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == e["file_sha256"], f
+        a = c2.loadBmpImage(data)
+        b, _ = orc.bmp_decode(data)
+        assert a.shape == (e["height"], e["width"], 3) and a.dtype == np.float32, f
+        assert np.array_equal(a, b), f
+        assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == e["decoded_sha256"], f
+        assert a.min() >= 0.0 and a.max() <= 1.0
+
+
 def test_bmp_rejects_what_the_reference_cannot_decode():
     hdr = bytearray(70)
     hdr[0:2] = b"BM"
