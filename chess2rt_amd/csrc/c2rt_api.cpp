@@ -25,7 +25,7 @@
 
 using namespace c2rt;
 
-constexpr int kMaxChunks = 8;      /* row chunks of a host-output frame */
+constexpr int kMaxChunks = 16;     /* row chunks of a host-output frame */
 
 struct c2rt_ctx {
     int device = 0;
@@ -39,6 +39,7 @@ struct c2rt_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;              /* D2H of finished chunks */
     hipEvent_t chunk_done[kMaxChunks] = {};
+    hipStream_t copy_stream2 = nullptr; /* chunks alternate between two copy streams (two SDMA engines) */
     std::vector<std::pair<float *, size_t>> pinned; /* c2rt_pin_host_buffer */
 
     bool has_scene = false;
@@ -613,6 +614,7 @@ int c2rt_init(int device, c2rt_ctx **out)
     HIP_TRY(ctx, hipSetDevice(device));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking));
     for (int i = 0; i < kMaxChunks; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chunk_done[i], hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
@@ -690,6 +692,7 @@ void c2rt_destroy(c2rt_ctx *ctx)
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->copy_stream2) { (void)hipStreamSynchronize(ctx->copy_stream2); (void)hipStreamDestroy(ctx->copy_stream2); }
     for (hipEvent_t e : ctx->chunk_done)
         if (e) (void)hipEventDestroy(e);
     for (const auto &pb : ctx->pinned) (void)hipHostUnregister(pb.first);
@@ -1026,6 +1029,30 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
  * stop flag is polled between chunks (finer than the reference's between-pass polling).  Into
  * pageable memory: one launch, one copy — chunked copies into pageable memory are slower than one
  * (measured).  ctx->frame holds the float rows, followed by the packed rows for the RGB32 form. */
+/* Host-output pipeline parameters (defaults measured on MI355X, profiles/r03_variants.md); the environment
+ * variables exist for that measurement: C2RT_HOST_CHUNK_MB, C2RT_HOST_FIRST_FRAC, C2RT_HOST_COPY_STREAMS,
+ * C2RT_HOST_DIRECT_STORE. */
+struct HostKnobs {
+    size_t chunk_bytes = 16u << 20; /* 4K float frame, ms: 2 MB 2.42, 4 MB 2.41, 8 MB 2.12, 16 MB 2.02, 24 MB 2.11, 32 MB 2.19 (copy alone: 1.75) */
+    double first_frac = 1.0;        /* a smaller first chunk: no gain (the pipeline is copy-bound from the first copy on) */
+    int copy_streams = 1;           /* two copy streams: no gain */
+    /* kernel stores straight into the page-locked frame: 0 never, 1 the display-word frame (4 B/pixel: 1.30 ms
+     * against 1.60 chunked; the float frame's 12-byte stores reach only 44 GB/s: 2.27 against 2.02), 2 both */
+    int direct_store = 1;
+};
+static const HostKnobs &host_knobs()
+{
+    static const HostKnobs k = [] {
+        HostKnobs v;
+        if (const char *e = std::getenv("C2RT_HOST_CHUNK_MB")) { const double mb = std::atof(e); if (mb >= 0.25 && mb <= 1024) v.chunk_bytes = (size_t)(mb * (1u << 20)); }
+        if (const char *e = std::getenv("C2RT_HOST_FIRST_FRAC")) { const double f = std::atof(e); if (f > 0 && f <= 1) v.first_frac = f; }
+        if (const char *e = std::getenv("C2RT_HOST_COPY_STREAMS")) v.copy_streams = std::atoi(e) > 1 ? 2 : 1;
+        if (const char *e = std::getenv("C2RT_HOST_DIRECT_STORE")) v.direct_store = std::atoi(e);
+        return v;
+    }();
+    return k;
+}
+
 /* the blocking entry points: nothing of an earlier stream-async frame of this context may still be in flight
  * (it would share the retry list and the counters), and nothing is in flight when they return */
 static int drain_inflight(c2rt_ctx *ctx)
@@ -1041,52 +1068,85 @@ static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2r
     if (const int st = drain_inflight(ctx)) return st;
     RenderParams p;
     fill_params(ctx, cam, opts, p);
-    p.out = ctx->frame;
     ctx->counters_valid = false;
     if (opts->count_rays) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
         p.ray_counters = ctx->counters;
     }
     const uint32_t rows = p.local_rows;
-    const size_t row_px = opts->width, row_floats = row_px * 3;
-    uint32_t *packed = reinterpret_cast<uint32_t *>(ctx->frame + (size_t)rows * row_floats);
+    const size_t row_px = opts->width;
+    /* the display frame leaves the render kernel encoded (RenderParams::out_rgb32): 4 B per pixel in the
+     * staging buffer, no float frame, no second kernel */
+    const size_t px_bytes = out_rgb ? 3 * sizeof(float) : sizeof(uint32_t);
+    char *staging = reinterpret_cast<char *>(ctx->frame);
+    if (out_rgb) {
+        p.out = ctx->frame;
+    } else {
+        p.out = nullptr;
+        p.out_rgb32 = reinterpret_cast<uint32_t *>(ctx->frame);
+        p.srgb_lut = ctx->srgb_lut;
+    }
     char *dst = out_rgb ? reinterpret_cast<char *>(out_rgb) : reinterpret_cast<char *>(out_rgb32);
-    const size_t dst_row_bytes = out_rgb ? row_floats * sizeof(float) : row_px * sizeof(uint32_t);
+    const size_t dst_row_bytes = row_px * px_bytes;
     bool is_pinned = false;
     for (const auto &pb : ctx->pinned)
         is_pinned = is_pinned || (dst >= reinterpret_cast<char *>(pb.first) &&
                                   dst + (size_t)rows * dst_row_bytes <= reinterpret_cast<char *>(pb.first) + pb.second);
-    /* one chunk per ~8 MB crossing PCIe, at most 8: enough copies in flight to hide them behind the
-     * kernels, few enough launches that their tails do not add up (measured on 4K frames: 8 chunks for
-     * the 99.5 MB float frame, 4 for the 33 MB RGB32 one) */
+    const KernelVariant variant = variant_of(ctx, cam);
+    const HostKnobs &knobs = host_knobs();
+    if (is_pinned && knobs.direct_store >= (out_rgb ? 2 : 1)) {
+        /* the kernel stores straight into the page-locked host frame over PCIe while it renders */
+        void *mapped = nullptr;
+        if (hipHostGetDevicePointer(&mapped, dst, 0) == hipSuccess && mapped) {
+            if (out_rgb) p.out = static_cast<float *>(mapped); else p.out_rgb32 = static_cast<uint32_t *>(mapped);
+            if (stop_flag && *stop_flag) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested during the frame");
+            const int e = launch_frame(ctx, p, variant, ctx->stream);
+            if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (opts->count_rays) { ctx->counters_valid = true; ctx->counters_stream = ctx->stream; }
+            return C2RT_OK;
+        }
+        (void)hipGetLastError();
+    }
+    /* Into a page-locked frame: row chunks, chunk i crossing PCIe on a copy stream while chunk i+1 renders.
+     * The copy (99.5 MB of float frame at ~57 GB/s = 1.75 ms at 4K) is longer than the render (1.15 ms), so
+     * the frame time is the first chunk's render + the copies back to back + whatever keeps them from being
+     * back to back: a SMALL first chunk, then equal ones; two copy streams so that one copy's setup hides
+     * behind the other's transfer.  Into pageable memory: one launch, one copy (chunked copies into pageable
+     * memory are slower than one, measured).  The stop flag is polled between chunks. */
     const size_t total_bytes = (size_t)rows * dst_row_bytes;
-    uint32_t want = (uint32_t)((total_bytes + (8u << 20) - 1) / (8u << 20));
+    uint32_t want = (uint32_t)((total_bytes + knobs.chunk_bytes - 1) / knobs.chunk_bytes);
     if (want < 1) want = 1;
-    if (want > (uint32_t)kMaxChunks) want = kMaxChunks;
+    if (want > (uint32_t)kMaxChunks - 1) want = kMaxChunks - 1;
     uint32_t chunk = is_pinned ? ((rows + want - 1) / want + kTileH - 1) / kTileH * kTileH : rows;
     if (chunk < 64) chunk = 64;
-    const KernelVariant variant = variant_of(ctx, cam);
+    uint32_t first = chunk;
+    if (is_pinned && want > 1) {
+        first = (uint32_t)(chunk * knobs.first_frac + kTileH - 1) / kTileH * kTileH;
+        if (first < 64) first = 64;
+        if (first > chunk) first = chunk;
+    }
     bool cancelled = false;
     int n_chunks = 0;
-    for (uint32_t off = 0; off < rows && n_chunks < kMaxChunks; off += chunk, ++n_chunks) {
+    for (uint32_t off = 0; off < rows && n_chunks < kMaxChunks; ++n_chunks) {
         if (stop_flag && *stop_flag) { cancelled = true; break; }
+        uint32_t n = n_chunks == 0 ? first : chunk;
+        if (n > rows - off || n_chunks == kMaxChunks - 1) n = rows - off;
         p.row_offset = off;
-        p.local_rows = rows - off < chunk ? rows - off : chunk;
-        p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
-        if (chunk < rows) p.row_group_start = 0; /* the rotation is relative to the whole frame's rows */
-        int e = launch_frame(ctx, p, variant, ctx->stream);
+        p.local_rows = n;
+        p.tiles_y = (n + kTileH - 1) / kTileH;
+        if (n < rows) p.row_group_start = 0; /* the rotation is relative to the whole frame's rows */
+        const int e = launch_frame(ctx, p, variant, ctx->stream);
         if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
-        const void *src = ctx->frame + off * row_floats;
-        if (out_rgb32) {
-            e = launch_encode_rgb32(ctx->frame + off * row_floats, packed + off * row_px, (uint64_t)p.local_rows * row_px, ctx->srgb_lut, ctx->stream);
-            if (e != 0) return fail(ctx, C2RT_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
-            src = packed + off * row_px;
-        }
+        hipStream_t cs = (knobs.copy_streams > 1 && (n_chunks & 1)) ? ctx->copy_stream2 : ctx->copy_stream;
         HIP_TRY(ctx, hipEventRecord(ctx->chunk_done[n_chunks], ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_done[n_chunks], 0));
-        HIP_TRY(ctx, hipMemcpyAsync(dst + off * dst_row_bytes, src, (size_t)p.local_rows * dst_row_bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->chunk_done[n_chunks], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(dst + (size_t)off * dst_row_bytes, staging + (size_t)off * dst_row_bytes, (size_t)n * dst_row_bytes,
+                                    hipMemcpyDeviceToHost, cs));
+        off += n;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream2));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (cancelled) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested during the frame");
     if (opts->count_rays) {
@@ -1144,20 +1204,20 @@ static int render_to_host_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, con
         if (hipSetDevice(c->device) != hipSuccess) { st = fail(ctx, C2RT_ERR_HIP, "hipSetDevice(%d)", c->device); break; }
         const size_t px = (size_t)rows * W;
         if ((st = ensure_staging(c, px * 3 + (out_rgb32 ? px : 0))) != C2RT_OK) { st = fail(ctx, st, "slot %u: %s", d, c->err.c_str()); break; }
-        p.out = c->frame;
+        if (out_rgb) {
+            p.out = c->frame;
+        } else { /* display words straight out of the render kernel (RenderParams::out_rgb32) */
+            p.out = nullptr;
+            p.out_rgb32 = reinterpret_cast<uint32_t *>(c->frame);
+            p.srgb_lut = c->srgb_lut;
+        }
         if (opts->count_rays) {
             if (hipMemsetAsync(c->counters, 0, 3 * sizeof(unsigned long long), c->stream) != hipSuccess) { st = fail(ctx, C2RT_ERR_HIP, "counter reset"); break; }
             p.ray_counters = c->counters;
         }
-        int e = launch_frame(c, p, variant, c->stream);
+        const int e = launch_frame(c, p, variant, c->stream);
         if (e != 0) { st = fail(ctx, C2RT_ERR_HIP, "render kernel launch (slot %u): %s", d, hipGetErrorString((hipError_t)e)); break; }
         const char *src = reinterpret_cast<const char *>(c->frame);
-        if (out_rgb32) {
-            uint32_t *packed = reinterpret_cast<uint32_t *>(c->frame + px * 3);
-            e = launch_encode_rgb32(c->frame, packed, px, c->srgb_lut, c->stream);
-            if (e != 0) { st = fail(ctx, C2RT_ERR_HIP, "encode launch (slot %u): %s", d, hipGetErrorString((hipError_t)e)); break; }
-            src = reinterpret_cast<const char *>(packed);
-        }
         /* this slot's strips: d, d+G, ...; all full except possibly the frame's last strip */
         const uint32_t mine = (n_strips - d + G - 1) / G;
         const bool owns_partial = rem != 0 && (n_strips - 1) % G == d;
@@ -1297,6 +1357,23 @@ int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
     return render_to_host(ctx, cam, opts, out_rgb, nullptr, stop_flag);
 }
 
+/* nothing of this context (any stream of any device slot) may still be copying into a buffer whose pages are
+ * about to be unlocked */
+static int quiesce(c2rt_ctx *ctx)
+{
+    if (const int st = drain_inflight(ctx)) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream2));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (c2rt_ctx *c : ctx->peers) {
+        HIP_TRY(ctx, hipSetDevice(c->device));
+        HIP_TRY(ctx, hipStreamSynchronize(c->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(c->copy_stream));
+    }
+    if (!ctx->peers.empty()) HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return C2RT_OK;
+}
+
 int c2rt_pin_host_buffer(c2rt_ctx *ctx, float *out_rgb, size_t bytes)
 {
     if (!ctx) return C2RT_ERR_INVALID_ARG;
@@ -1307,13 +1384,13 @@ int c2rt_pin_host_buffer(c2rt_ctx *ctx, float *out_rgb, size_t bytes)
             if (ctx->pinned[i].second == bytes) return C2RT_OK;
             /* the same address with another size (a re-allocated frame buffer): register afresh, so that
              * the recorded range is exactly what is page-locked */
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+            if (const int st = quiesce(ctx)) return st;
             HIP_TRY(ctx, hipHostUnregister(out_rgb));
             ctx->pinned.erase(ctx->pinned.begin() + (long)i);
             break;
         }
     /* portable: page-locked for every device slot of a multi-device context */
-    HIP_TRY(ctx, hipHostRegister(out_rgb, bytes, hipHostRegisterPortable));
+    HIP_TRY(ctx, hipHostRegister(out_rgb, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
     ctx->pinned.emplace_back(out_rgb, bytes);
     return C2RT_OK;
 }
@@ -1324,7 +1401,7 @@ int c2rt_unpin_host_buffer(c2rt_ctx *ctx, float *out_rgb)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (size_t i = 0; i < ctx->pinned.size(); ++i)
         if (ctx->pinned[i].first == out_rgb) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+            if (const int st = quiesce(ctx)) return st;
             HIP_TRY(ctx, hipHostUnregister(out_rgb));
             ctx->pinned.erase(ctx->pinned.begin() + (long)i);
             return C2RT_OK;

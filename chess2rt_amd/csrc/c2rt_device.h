@@ -211,6 +211,10 @@ struct RenderParams {
      * per tile {shader-clock cycles the wave spent on it, class bits}; never read by the product build */
     uint32_t *tile_stats;
     float *out;                    /* local_rows * width * 3 floats */
+    /* non-null: the frame leaves the kernel display-encoded instead (Color.toRGB32 through the reference's
+     * 4097-entry sRGB table, one 32-bit word per pixel, same indexing as `out`, which is then unused) */
+    uint32_t *out_rgb32;
+    const uint8_t *srgb_lut;
     unsigned long long *ray_counters; /* [3] primary rays, shadow rays, CSG hit lists that reached the cap (nullable) */
     /* tiles that the production instances rendered a second time through the compiler's divide / sqrt
      * because a lane met an operand outside a lean window (c2rt_trace.inc); cumulative, never null */
