@@ -395,6 +395,111 @@ def measure(torch, dist, pipe, steps, warmup, world, dev):
     return float(el.item()), kernel_ms
 
 
+def measure_pipelined(torch, c2, ctx, scene, cam, opts, steps, warmup, dev):
+    """N=1: TWO frames in flight — two contexts (frames of one context are ordered, include/c2rt.h), two streams,
+    two output buffers, frames enqueued alternately: a frame's launch gap and the under-filled tail of its grid
+    are covered by the other frame's waves.  Throughput of a frame SEQUENCE (an animation, the GUI's camera loop
+    rendered ahead); a single frame's latency is the serial figure.  Returns seconds for `steps` frames."""
+    ctx2 = c2.Context(dev.index or 0)
+    try:
+        ctx2.uploadScene(scene.desc)
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        ctxs = [ctx, ctx2]
+        outs = [torch.empty((opts.height, opts.width, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+
+        def frame(i):
+            ctxs[i & 1].renderFrameDevice(cam, opts, outs[i & 1].data_ptr(), streams[i & 1].cuda_stream)
+
+        for i in range(2 * max(1, warmup)):
+            frame(i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            frame(i)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+    finally:
+        ctx2.close()
+
+
+def smi_sample():
+    """GPU clock / power / temperature as the box's SMI tool reports them right now (None when there is none)."""
+    import shutil
+    import subprocess
+
+    for tool, args in (("amd-smi", ["metric", "--clock", "--power", "--json"]), ("rocm-smi", ["--showclocks", "--showpower", "--showtemp", "--json"])):
+        exe = shutil.which(tool) or (os.path.join("/opt/rocm/bin", tool) if os.path.exists(os.path.join("/opt/rocm/bin", tool)) else None)
+        if not exe:
+            continue
+        try:
+            out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=20)
+            if out.returncode == 0 and out.stdout.strip():
+                text = out.stdout.strip()
+                start = min(i for i in (text.find("{"), text.find("[")) if i >= 0)
+                return {"tool": tool, "raw": summarise_smi(json.loads(text[start:]))}
+        except Exception as e:  # noqa: BLE001 — diagnostics only
+            return {"tool": tool, "error": str(e)[:200]}
+    return None
+
+
+def summarise_smi(data):
+    """Flattens an SMI JSON document to the handful of numeric leaves whose key mentions clock / power / temperature
+    (tool versions differ in layout; keys are kept as paths)."""
+    found = {}
+
+    def walk(node, path):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                walk(v, path + [str(k)])
+        elif isinstance(node, list):
+            for i, v in enumerate(node[:2]):
+                walk(v, path + [str(i)])
+        else:
+            key = "/".join(path).lower()
+            if any(w in key for w in ("sclk", "gfx", "power", "temp", "mclk")) and len(found) < 24:
+                found["/".join(path)] = node
+    walk(data, [])
+    return found
+
+
+def sustained_leg(torch, pipe, dev, seconds=3.0):
+    """>= `seconds` of back-to-back frames of the headline workload, OUTSIDE the timed region: ms/frame of the
+    first and the last 10 % (HIP events around batches of frames), and the SMI tool's clocks / power sampled
+    while the GPU is under that load — a kernel at VALU busy 0.9 on fp64 is a candidate for throttling; this is
+    where it would show."""
+    stream = pipe.stream
+    pipe.step()
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    for _ in range(10):
+        pipe.step()
+    torch.cuda.synchronize(dev)
+    per = (time.perf_counter() - t) / 10
+    batch = max(1, int(0.02 / per))                      # ~20 ms of frames per event pair
+    n_batches = max(10, int(seconds / (batch * per)) + 1)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_batches + 1)]
+    smi = {}
+    t0 = time.perf_counter()
+    ev[0].record(stream)
+    for b in range(n_batches):
+        for _ in range(batch):
+            pipe.step()
+        ev[b + 1].record(stream)
+        if b == n_batches // 2:
+            ev[b + 1].synchronize()                       # the host catches up, then asks the SMI tool while frames keep coming
+            for _ in range(batch * 4):
+                pipe.step()
+            smi = smi_sample() or {}
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    ms = [ev[b].elapsed_time(ev[b + 1]) / batch for b in range(n_batches) if b != n_batches // 2 + 0]
+    k = max(1, len(ms) // 10)
+    first, last = statistics.mean(ms[:k]), statistics.mean(ms[-k:])
+    return {"seconds": wall, "frames": n_batches * batch + batch * 4, "ms_per_frame_first_10pct": first, "ms_per_frame_last_10pct": last,
+            "ms_per_frame_mean": statistics.mean(ms), "last_over_first": last / first, "smi_under_load": smi or None,
+            "note": "back-to-back frames outside the timed region; HIP events every %d frames on the render stream" % batch}
+
+
 def phase_probe(torch, dist, pipe, world, dev, n=3):
     """N>1: host-clocked phases of a SERIAL frame (barrier + device sync between phases), mean of n:
     render (every rank's strips), exchange (gather or per-strip send/recv, all ranks), de-interleave
@@ -478,6 +583,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="N=1: skip the host-output (PCIe-inclusive) timings")
+    ap.add_argument("--no-sustained", action="store_true", help="N=1: skip the >= 3 s sustained leg")
+    ap.add_argument("--no-pipelined", action="store_true", help="N=1: skip the two-frames-in-flight figures")
     ap.add_argument("--strip-height", type=int, default=0, help="rows per strip (multiple of 8); default 8 (gather) / 32 (p2p: one message per strip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = single-GPU rehearsal of the N>1 flow: host-staged gather, every rank on device 0")
@@ -571,9 +678,12 @@ def main():
         primary, shadow = count_rays(torch, dist, ctx, scene, cam, pipe, taps, world, rank, dev)
         elapsed, kernel_ms = measure(torch, dist, pipe, steps, warmup, world, dev)
         phases = phase_probe(torch, dist, pipe, world, dev) if world > 1 else None
+        pipelined = None
+        if world == 1 and not args.no_pipelined:
+            pipelined = measure_pipelined(torch, c2, ctx, scene, cam, pipe.opts, steps, warmup, dev)
         return dict(scene=scene, cam=cam, pipe=pipe, scene_file=scene_file, width=width, height=height, taps=taps, dof=dof,
                     primary=primary, shadow=shadow, elapsed=elapsed, kernel_ms=kernel_ms, steps=steps, phases=phases,
-                    calib=calib)
+                    calib=calib, pipelined=pipelined)
 
     def check_frame(r):
         """N>1: the frame rank 0 assembled from every rank's strips must equal rank 0's own render of the WHOLE
@@ -630,6 +740,9 @@ def main():
                 "kernel_ms": o["kernel_ms"],
                 "rays_per_frame": rays,
             }
+            if o["pipelined"]:
+                others[name]["two_frames_in_flight"] = {"Mray_per_s": rays * o["steps"] / o["pipelined"] / 1e6,
+                                                         "ms_per_frame": o["pipelined"] / o["steps"] * 1e3}
         # leave the context on the headline scene for the CPU baseline below
         ctx.uploadScene(r["scene"].desc)
 
@@ -652,7 +765,7 @@ def main():
         alg_bytes = pipe.my_rows * r["width"] * 12 + tex_bytes
         achieved = alg_bytes / (r["kernel_ms"] * 1e-3) / 1e9
         # PMC counts come from a committed profile and are only valid for the kernels they were taken on
-        traffic = valu_insts = None
+        traffic = valu_insts = fp64_insts = None
         profile_state = "absent"
         khash = kernel_source_hash()
         prof = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
@@ -662,6 +775,7 @@ def main():
                 if prof_data.get("kernel_source_hash") == khash:
                     traffic = prof_data.get("hbm_bytes_per_launch")
                     valu_insts = prof_data.get("valu_insts_per_launch")
+                    fp64_insts = prof_data.get("fp64_wave_insts_per_launch")
                     profile_state = "matches the built kernels (%s)" % khash
                 else:
                     profile_state = "stale: taken on kernels %s, this tree is %s — counts withheld" % (
@@ -729,6 +843,22 @@ def main():
             slots = valu_insts * 64 / (r["kernel_ms"] * 1e-3) / 1e12
             out["roofline"]["valu"] = {"achieved": slots, "peak": VALU_PEAK_TSLOTS, "unit": "T lane-slots/s", "frac": slots / VALU_PEAK_TSLOTS,
                                        "insts_per_launch": valu_insts, "source": "SQ_INSTS_VALU, profiles/traffic_%s.json" % args.workload}
+        if fp64_insts:
+            # the fp64 arithmetic this kernel EXECUTES: PMC wave-instruction counts (add, mul, fma, rcp/rsq seeds) of THESE
+            # kernels (hash checked) x 64 lanes over the live kernel time, against one fp64 operation per lane slot
+            lane_ops = sum(fp64_insts.values()) * 64
+            rate = lane_ops / (r["kernel_ms"] * 1e-3) / 1e12
+            out["roofline"]["fp64_executed"] = {"achieved": rate, "peak": FP64_PEAK_TOPS, "unit": "T fp64 lane-instructions/s", "frac": rate / FP64_PEAK_TOPS,
+                                                "wave_insts_per_launch": fp64_insts, "source": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, profiles/traffic_%s.json" % args.workload,
+                                                "note": "an fma counts once; the rest of the VALU stream (roofline.valu) is compares, selects, moves, integer and fp32 work"}
+        if r.get("pipelined"):
+            out["config"]["two_frames_in_flight"] = {"Mray_per_s": rays_per_frame * r["steps"] / r["pipelined"] / 1e6, "ms_per_frame": r["pipelined"] / r["steps"] * 1e3,
+                                                     "note": "two contexts on two streams, frames enqueued alternately: launch gaps and grid tails filled by the other frame; never `value`"}
+        if world == 1 and not args.no_sustained:
+            try:
+                out["sustained"] = sustained_leg(torch, pipe, dev)
+            except Exception as e:  # noqa: BLE001
+                print("bench.py: sustained leg failed (%s)" % e, file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 base, ops = cpu_baseline(c2, r["scene_file"], r["width"], r["height"], r["taps"], r["dof"], rays_per_frame)
@@ -740,11 +870,11 @@ def main():
             # oracle), over the live kernel time, against the non-fused fp64 vector peak
             if ops:
                 tops = ops["fp64"] / (r["kernel_ms"] * 1e-3) / 1e12
-                out["roofline"]["flops"] = {
-                    "achieved": tops, "peak": FP64_PEAK_TOPS, "unit": "T fp64 op/s (non-fused)", "frac": tops / FP64_PEAK_TOPS,
-                    "algorithmic_fp64_ops_per_launch": ops["fp64"], "ops": ops,
-                    "note": "reference op count / kernel time: the kernel skips part of that work exactly (culling masks, "
-                            "bounding rejects, sign tests, lazy u,v), so this can exceed the fraction of issue slots it fills",
+                out["roofline"]["reference_work_rate"] = {
+                    "value": tops, "unit": "T reference fp64 op/s", "reference_fp64_ops_per_launch": ops["fp64"], "ops": ops,
+                    "note": "the fp64 operations the REFERENCE's source executes for this frame (instrumented oracle; div, sqrt, libm = 1 each) "
+                            "over the kernel time.  Not a fraction of peak: the kernel skips part of that work exactly (culling masks, bounding "
+                            "rejects, sign tests, deferred attributes) — what it executes is roofline.fp64_executed",
                 }
         print(json.dumps(out), flush=True)
 

@@ -2,7 +2,7 @@
 # VALU instruction mix of one workload's frame kernel: scripts/pmc_mix.sh <workload>
 export TMPDIR=/tmp
 W=$1
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-others --no-boundary --workload $W"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-others --no-boundary --no-sustained --no-pipelined --workload $W"
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
             "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT" \
             "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SENDMSG SQ_INSTS_VSKIPPED"; do

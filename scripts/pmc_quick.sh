@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 for w in $1; do
   rm -rf gpurun_out/pq_$w
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pq_$w -o pmc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-others --no-boundary --workload $w > gpurun_out/pq_$w.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pq_$w -o pmc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-others --no-boundary --no-sustained --no-pipelined --workload $w > gpurun_out/pq_$w.log 2>&1
   python3 - "$w" <<'PY'
 import csv,sys,collections,statistics
 w=sys.argv[1]

@@ -97,6 +97,16 @@ if workload and "hbm_bytes_per_launch" in d and "SQ_INSTS_VALU" in c:
         "valu_insts_per_wave": d.get("valu_insts_per_wave"),
         "kernel_avg_us": summ["avg_duration_us_timed"],
     }
+    # the fp64 arithmetic the kernel actually EXECUTES (wave-instructions per launch; x 64 lanes = lane-operations),
+    # for bench.py's roofline.fp64_executed
+    f64 = {k: c.get("SQ_INSTS_VALU_%s_F64" % k) for k in ("ADD", "MUL", "FMA", "TRANS")}
+    if all(v is not None for v in f64.values()):
+        tr_json["fp64_wave_insts_per_launch"] = {k.lower(): v for k, v in f64.items()}
+    mix = {k: c.get(k) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+                                 "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM",
+                                 "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")}
+    if any(v is not None for v in mix.values()):
+        tr_json["other_wave_insts_per_launch"] = {k.replace("SQ_INSTS_", "").lower(): v for k, v in mix.items() if v is not None}
     with open(os.path.join(dst, "traffic_%s.json" % workload), "w") as f:
         json.dump(tr_json, f, indent=1)
 print(json.dumps(summ, indent=1))
