@@ -40,6 +40,20 @@ __device__ __noinline__ double c2_atan2(double a, double b) { return atan2(a, b)
 __device__ __noinline__ double c2_asin(double a) { return asin(a); }
 __device__ __noinline__ double c2_sin(double a) { return sin(a); }
 __device__ __noinline__ double c2_cos(double a) { return cos(a); }
+/* Sphere.intersect's u,v (rt/geometry.d:118-120) out of line as well: the x87 emulation (x87.h) is ~500 integer
+ * instructions with ~40 live registers, reached by textured sphere hits only; inlined (twice: lean:: and exact::)
+ * it was where the headline instance spilled. */
+struct UV { double u, v; };
+__device__ __noinline__ UV c2_sphere_uv(double dx, double dz, double w)
+{
+    constexpr double PI = 3.14159265358979323846;
+    const double angle = atan2(dz, dx);
+    const double as = asin(w);
+    UV r;
+    r.u = fabs(angle) <= 4.0 ? x87_sphere_u(angle) : (PI + angle) / (2 * PI);
+    r.v = fabs(as) <= 2.0 ? x87_sphere_v(as) : 1.0 - (PI / 2 + as) / PI;
+    return r;
+}
 /* Register budget per kernel instance, as waves per SIMD (512 VGPRs per lane and SIMD: 128 at 4 waves,
  * 168 at 3, 256 at 2).  With no hint hipcc takes all 512 registers and runs one wave per SIMD (1.8x
  * slower).  Chosen per instance from the compiler's resource remarks (profiles/r02_resource_usage.txt)
@@ -84,6 +98,13 @@ constexpr bool kLean = false;
 #ifndef C2RT_LEAN
 #define C2RT_LEAN 1 /* 0: the production instances run exact:: only (A/B builds) */
 #endif
+/* The deepest CSG nesting whose instances carry the lean:: copy.  Depth 4 does not: at two waves per SIMD it is
+ * bound by latency, not by VALU issue (lean:: 10.39 ms against 10.42 on csg_stress), and with both copies in one
+ * kernel it spilled 21 VGPRs (96 B of scratch per lane, 1.4 GB of scratch writes per frame) where exact:: alone
+ * fits its 256 registers with none. */
+#ifndef C2RT_LEAN_MAX_LEVELS
+#define C2RT_LEAN_MAX_LEVELS 3
+#endif
 typedef const RenderParams __attribute__((address_space(4))) *KArgs;
 
 /* One tile: optimistically through lean::, and again through exact:: — by the same wave, with all of its
@@ -93,7 +114,7 @@ typedef const RenderParams __attribute__((address_space(4))) *KArgs;
 template <int LEVELS, int DOF, bool MLC, bool PO, bool CNT>
 DEV void render_one(const RenderParams &P, KArgs K, const uint32_t b)
 {
-    if constexpr (CNT || !C2RT_LEAN) {
+    if constexpr (CNT || !C2RT_LEAN || LEVELS > C2RT_LEAN_MAX_LEVELS) {
         exact::render_tile<LEVELS, DOF, MLC, PO, CNT>(P, (exact::KArgs)K, b);
     } else {
         if (!P.force_exact) { /* wave-uniform */
