@@ -45,7 +45,7 @@ $(LIBNAME): $(KOBJS) $(HOBJS)
 
 # device check of fp64_lean.h against the compiler's own divide / sqrt expansions (tests/test_gpu_parity.py runs it)
 tests/fp64_lean_check: tests/fp64_lean_check.hip $(CSRC)/fp64_lean.h
-	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 $(FPFLAGS) $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt $< -o $@
 
 # CPU oracle: plain C restatement of the reference algorithm (tests only)
 oracle/libc2rt_oracle.so: oracle/c2rt_oracle.c oracle/c2rt_oracle.h include/c2rt.h

@@ -824,6 +824,16 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         /* lightColor.intensity() != 0 — rt/shader.d:88, rt/color.d:141-144 */
         const float intensity = (d.color[0] + d.color[1] + d.color[2]) / 3;
         d.lit = intensity != 0 ? 1u : 0u;
+        /* bit 1: every channel is +0 or a finite float within 2^+-60 — the numerators of lean::'s fp32 division
+         * by the squared distance need no test on the device (c2rt_trace.inc, shade) */
+        bool chan_ok = true;
+        for (int c = 0; c < 3; ++c) {
+            uint32_t bits;
+            std::memcpy(&bits, &d.color[c], 4);
+            const float a = std::fabs(d.color[c]);
+            chan_ok = chan_ok && (bits == 0u || (a >= 0x1p-60f && a < 0x1p60f));
+        }
+        if (chan_ok) d.lit |= 2u;
     }
 
     /* nodes */

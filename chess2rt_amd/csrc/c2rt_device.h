@@ -132,7 +132,7 @@ struct alignas(16) DevTex {        /* 144 B */
 struct alignas(16) DevLight {      /* 48 B */
     double pos[3];
     float color[3];                /* lightColor * lightPower (rt/light.d:11-14) */
-    uint32_t lit;                  /* intensity(color) != 0 */
+    uint32_t lit;                  /* bit 0: intensity(color) != 0; bit 1: every channel +0 or within 2^+-60 (lean fp32 division) */
     uint32_t pad[2];
 };
 

@@ -153,6 +153,32 @@ LEAN_DEV void unit_len(double s, double &len, double &inv)
     inv = __longlong_as_double(0x3FF0000000000000ll + (long long)di);
 }
 
+/*
+ * fp32: `Color / float` (rt/color.d:128-132) divides three channels by one denominator.  hipcc's correctly rounded
+ * f32 division is v_div_scale x2, v_rcp_f32, fma, fma | mul, fma, fma, fma, v_div_fmas, v_div_fixup; without
+ * scaling (finite operands with 2^-60 <= |x| < 2^60, or a numerator of +0 over a positive denominator) that is
+ * the two functions below, and the first depends on the denominator only.
+ */
+LEAN_DEV bool f32_ok(float x)
+{
+    const uint32_t t = (__float_as_uint(x) << 1) - ((uint32_t)(127 - 60) << 24);
+    return t < ((uint32_t)120 << 24);
+}
+LEAN_DEV float rcp_refined_f32(float f)
+{
+    const float r = __builtin_amdgcn_rcpf(f);
+    const float e = __builtin_fmaf(-f, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+LEAN_DEV float div_with_f32(float a, float f, float r)
+{
+    float q = a * r;
+    float rem = __builtin_fmaf(-f, q, a);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-f, q, a);
+    return __builtin_fmaf(rem, r, q);
+}
+
 #undef LEAN_DEV
 
 } // namespace c2rt

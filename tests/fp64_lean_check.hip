@@ -85,6 +85,33 @@ __device__ inline void note(Report *r, int routine, double a, double b, double g
 /* the compiler's expansions, kept out of line so that nothing folds them with the lean forms */
 __device__ __noinline__ double ref_div(double a, double b) { return a / b; }
 __device__ __noinline__ double ref_sqrt(double x) { return sqrt(x); }
+__device__ __noinline__ float ref_div_f32(float a, float b) { return a / b; }
+
+/* a float with exponent uniform in [lo, hi) and the same mix of random / structured significands */
+__host__ __device__ inline float draw_f32(uint64_t key, int lo, int hi, bool positive)
+{
+    const uint64_t a = mix64(key ^ 0xF32F32F32ull), b = mix64(key + 0x51ull);
+    const int e = lo + (int)((a >> 8) % (uint64_t)(hi - lo));
+    uint32_t m = (uint32_t)b & 0x7FFFFFu;
+    const unsigned kind = (unsigned)(a & 0xFF);
+    if (kind < 64) {
+        const unsigned bit = (unsigned)((a >> 40) % 23);
+        switch (kind & 7) {
+        case 0: m = 0; break;
+        case 1: m = 0x7FFFFFu; break;
+        case 2: m = 1u << bit; break;
+        case 3: m = 0x7FFFFFu ^ (1u << bit); break;
+        case 4: m = 0x555555u; break;
+        case 5: m = 0x2AAAAAu; break;
+        case 6: m = (uint32_t)b & 0xFu; break;
+        default: m = 0x7FFFFFu - ((uint32_t)b & 0xFu); break;
+        }
+    }
+    const uint32_t bits = (positive ? 0u : (uint32_t)((a >> 63) << 31)) | ((uint32_t)(e + 127) << 23) | m;
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
 
 /* sample[]: the first `n_sample` items' operands and lean results, for the host comparison */
 __global__ void check_kernel(Report *rep, uint64_t seed, uint64_t per_thread, double *sample, uint64_t n_sample)
@@ -122,6 +149,20 @@ __global__ void check_kernel(Report *rep, uint64_t seed, uint64_t per_thread, do
             else got = ref_div(a, b);
             const double want = ref_div(a, b);
             if (bits_of(got) != bits_of(want)) note(rep, 9, a, b, got, want);
+        }
+        /* 11: fp32 — three numerators over one denominator (Color / float) */
+        {
+            const float f = draw_f32(key + 1, -60, 60, false);
+            const float r = rcp_refined_f32(f);
+            for (int c = 0; c < 3; ++c) {
+                float a = draw_f32(key + 2 + c, -60, 60, false);
+                if (((key >> 3) + c) % 11 == 0) a = 0.0f; /* a black channel */
+                float got = __uint_as_float(0x7fc0deadu);
+                if (f32_ok(f) && (f32_ok(a) || (__float_as_uint(a) == 0 && f > 0))) got = div_with_f32(a, f, r);
+                else got = ref_div_f32(a, f);
+                const float want = ref_div_f32(a, f);
+                if (__float_as_uint(got) != __float_as_uint(want)) note(rep, 11, a, f, got, want);
+            }
         }
         /* 2: sqrt, 3: the reciprocal length */
         {
@@ -176,7 +217,22 @@ __global__ void edges_kernel(Report *rep)
             }
         }
     }
+    /* fp32, exhaustive in the denominator's significand: every float in [1, 2) and in [2^20, 2^21) under 16
+     * numerators each (2 x 2^23 x 16 divisions, spread over the 256 threads of this block) */
+    for (uint32_t m = threadIdx.x; m < (1u << 23); m += blockDim.x)
+        for (int eb = 0; eb < 2; ++eb) {
+            const float f = __uint_as_float(((uint32_t)(eb ? 147 : 127) << 23) | m);
+            const float r = rcp_refined_f32(f);
+            for (int i = 0; i < 16; ++i) {
+                const float a = i == 0 ? 0.0f : draw_f32(0x1234ull * m + i, -20, 40, false);
+                const float got = div_with_f32(a, f, r), want = ref_div_f32(a, f);
+                if (__float_as_uint(got) != __float_as_uint(want)) note(rep, 11, a, f, got, want);
+            }
+        }
     if (threadIdx.x == 0) {
+        if (f32_ok(0.0f) || f32_ok(-0.0f) || f32_ok(1e-30f) || f32_ok(3e38f) || f32_ok(__uint_as_float(0x7f800000u)) ||
+            f32_ok(__uint_as_float(0x7fc00000u)) || !f32_ok(1.0f) || !f32_ok(-800000.0f) || !f32_ok(ldexpf(1.0f, -60)) || f32_ok(ldexpf(1.0f, 60)))
+            note(rep, 6, 0, 0, 3.0, 0.0);
         const double specials[] = {0.0, -0.0, 4.9e-324, 2.2250738585072009e-308, __longlong_as_double(0x7ff0000000000000ll),
                                    __longlong_as_double(0xfff0000000000000ll), __longlong_as_double(0x7ff8000000000000ll)};
         for (double v : specials)
@@ -233,18 +289,18 @@ int main(int argc, char **argv)
         volatile double ui = 1.0 / ul;
         if (!same(q0, p[2]) || !same(q1, p[5]) || !same(l, p[7]) || !same(li, p[8]) || !same(ul, p[10]) || !same(ui, p[11])) ++host_bad;
     }
-    const char *names[] = {"div_window", "div_tracer_range", "sqrt_lean", "inv_len", "renormalise", "unit_len_exhaustive", "window_edges", "", "", "div_by_rounded_reciprocal", "div_by_unit_len"};
+    const char *names[] = {"div_window", "div_tracer_range", "sqrt_lean", "inv_len", "renormalise", "unit_len_exhaustive", "window_edges", "", "", "div_by_rounded_reciprocal", "div_by_unit_len", "div_f32"};
     unsigned long long bad = host_bad;
     printf("{\"operands_per_routine\": %llu, \"host_sample\": %llu, \"host_mismatches\": %llu, \"not_near_one\": %llu",
            (unsigned long long)(per_thread * nthreads), (unsigned long long)n_sample, host_bad, h.mismatches[7]);
     printf(", \"inv_len_all_ones_significands\": %llu", h.mismatches[8]);
-    for (int r = 0; r < 11; ++r) {
+    for (int r = 0; r < 12; ++r) {
         if (!names[r][0]) continue;
         printf(", \"%s\": %llu", names[r], h.mismatches[r]);
         bad += h.mismatches[r];
     }
     printf("}\n");
-    for (int r = 0; r < 11; ++r)
+    for (int r = 0; r < 12; ++r)
         if (names[r][0] && h.mismatches[r])
             fprintf(stderr, "%s: first mismatch: operands %a %a -> got %a, want %a\n", names[r], h.first[r][0], h.first[r][1], h.first[r][2], h.first[r][3]);
     return bad ? 1 : 0;

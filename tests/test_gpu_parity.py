@@ -900,7 +900,7 @@ def test_fp64_lean_sequences_match_the_compilers_expansions_on_the_device():
     print(rep)
     assert rep["operands_per_routine"] >= 1 << 30 and rep["host_sample"] >= 1 << 20
     for k in ("div_window", "div_tracer_range", "sqrt_lean", "inv_len", "renormalise", "unit_len_exhaustive", "window_edges",
-              "div_by_rounded_reciprocal", "div_by_unit_len", "host_mismatches", "not_near_one"):
+              "div_by_rounded_reciprocal", "div_by_unit_len", "div_f32", "host_mismatches", "not_near_one"):
         assert rep[k] == 0, (k, rep)
     assert rep["inv_len_all_ones_significands"] > 0   # the patched tie case was exercised
 
