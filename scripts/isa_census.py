@@ -3,7 +3,9 @@
 statement each instruction was generated from (the most recent `.loc` line of a -gline-tables-only build; the
 whole trace is inlined into the kernel, so the line's enclosing function in c2rt_kernels.hip names the region).
 
-usage: isa_census.py <unit> <mangled-name-substring> [--md]
+usage: isa_census.py <unit> <mangled-name-substring> [lean|exact]
+The production instances hold the trace twice (c2rt_trace.inc: lean:: first, then — after the atomic that counts a
+redo — exact::); `lean` / `exact` restricts the census to that half.
 Builds build/isa/u<unit>g.s with the Makefile's flags + -gline-tables-only (code generation is unchanged).
 """
 import collections
@@ -14,6 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "chess2rt_amd/csrc/c2rt_kernels.hip")
+TRACE = os.path.join(ROOT, "chess2rt_amd/csrc/c2rt_trace.inc")
 
 
 def make_flags():
@@ -25,10 +28,10 @@ def make_flags():
     return flags
 
 
-def function_spans():
-    """(first line, last line, name) of every function body in the kernel source (brace matching from a
+def function_spans(path=None):
+    """(first line, last line, name) of every function body in a source file (brace matching from a
     line that looks like a definition at namespace scope)."""
-    lines = open(SRC).read().split("\n")
+    lines = open(path or SRC).read().split("\n")
     spans = []
     i = 0
     sig = re.compile(r"^(?:template\s*<[^>]*>\s*)?(?:DEV|__device__|__global__|static|inline|int|void)\b.*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;]*$")
@@ -89,6 +92,7 @@ def classify(op):
 
 def main():
     unit, pat = sys.argv[1], sys.argv[2]
+    half = sys.argv[3] if len(sys.argv) > 3 else None
     flags = make_flags()
     out = os.path.join(ROOT, "build", "isa", "u%sg.s" % unit)
     os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -97,7 +101,7 @@ def main():
           ["-DC2RT_UNIT=%s" % unit, "-gline-tables-only", "--offload-device-only", "-S", SRC, "-o", out, "-I" + os.path.join(ROOT, "include")]
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(SRC):
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-    spans = function_spans()
+    spans = {"c2rt_kernels.hip": function_spans(SRC), "c2rt_trace.inc": function_spans(TRACE)}
 
     files = {}
     for raw in open(out):
@@ -111,18 +115,21 @@ def main():
             return "x87.h (Sphere u,v in x87 extended precision)"
         if name == "fp64_lean.h":
             return "fp64_lean.h (lean divide / sqrt / reciprocal length)"
-        if name != "c2rt_kernels.hip":
+        if name not in spans:
             return "device libm / HIP headers"
-        for a, b, name in spans:
+        for a, b, fn in spans[name]:
             if a <= line <= b:
-                return name
-        return "vector helpers (D3 / F3 operators, dot, sqmag)" if line < 140 else "(file scope)"
+                return fn
+        if name == "c2rt_trace.inc":
+            return "vector helpers (D3 / F3 operators, dot, sqmag)" if line < 140 else "(file scope)"
+        return "kernel entry (c2rt_kernels.hip)"
 
     per_region = collections.defaultdict(collections.Counter)
     total = collections.Counter()
     inside = False
     cur = ("?", 0)
     kname = None
+    in_exact = False
     for raw in open(out):
         s = raw.strip()
         if not inside:
@@ -139,17 +146,23 @@ def main():
         if not s or s.startswith(".") or s.startswith(";") or s.endswith(":"):
             continue
         op = s.split()[0]
+        if op.startswith("global_atomic_add_x2"):
+            in_exact = True      # render_one: atomicAdd(P.redo_counter) sits between the two copies
+        if half == "lean" and in_exact:
+            continue
+        if half == "exact" and not in_exact:
+            continue
         c = classify(op)
         per_region[region_of(*cur)][c] += 1
         total[c] += 1
     n = sum(total.values())
-    print("# Static ISA census of `%s`\n" % kname)
+    print("# Static ISA census of `%s`%s\n" % (kname, " — the %s:: half" % half if half else ""))
     print("%d instructions.  By class:\n" % n)
     print("| class | instructions | share |\n|---|---|---|")
     for name, _ in CLASSES + [("other", None)]:
         if total[name]:
             print("| %s | %d | %.1f %% |" % (name, total[name], 100.0 * total[name] / n))
-    print("\nBy source region (function of c2rt_kernels.hip the statement belongs to), largest first; columns: all / fp64 arithmetic / "
+    print("\nBy source region (function of c2rt_trace.inc / c2rt_kernels.hip the statement belongs to), largest first; columns: all / fp64 arithmetic / "
           "fp64 seeds / divide-sqrt scaffolding / compares / selects / moves (32+64) / spill lanes / SALU+branch+wait:\n")
     print("| region | all | fp64 arith | seeds | scaffolding | fp64 cmp | selects | moves | spill lanes | scalar |\n|---|---|---|---|---|---|---|---|---|---|")
     for reg, cnt in sorted(per_region.items(), key=lambda kv: -sum(kv[1].values())):
