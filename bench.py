@@ -496,7 +496,8 @@ def sustained_leg(torch, pipe, dev, seconds=3.0):
             smi = smi_sample() or {}
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    ms = [ev[b].elapsed_time(ev[b + 1]) / batch for b in range(n_batches) if b != n_batches // 2 + 0]
+    # (the interval after the SMI query holds the extra frames enqueued while the tool ran: not a batch)
+    ms = [ev[b].elapsed_time(ev[b + 1]) / batch for b in range(n_batches) if b not in (n_batches // 2, n_batches // 2 + 1)]
     k = max(1, len(ms) // 10)
     first, last = statistics.mean(ms[:k]), statistics.mean(ms[-k:])
     return {"seconds": wall, "frames": n_batches * batch + batch * 4, "ms_per_frame_first_10pct": first, "ms_per_frame_last_10pct": last,
@@ -684,7 +685,9 @@ def main():
         phases = phase_probe(torch, dist, pipe, world, dev) if world > 1 else None
         pipelined = None
         if world == 1 and not args.no_pipelined:
-            pipelined = measure_pipelined(torch, c2, ctx, scene, cam, pipe.opts, steps, warmup, dev)
+            # (at least ~50 ms of frames: a 20-frame burst of 0.09 ms frames measures its own ramp)
+            psteps = max(steps, min(500, int(0.05 / max(elapsed / steps, 1e-6))))
+            pipelined = measure_pipelined(torch, c2, ctx, scene, cam, pipe.opts, psteps, warmup, dev) * steps / psteps
         return dict(scene=scene, cam=cam, pipe=pipe, scene_file=scene_file, width=width, height=height, taps=taps, dof=dof,
                     primary=primary, shadow=shadow, elapsed=elapsed, kernel_ms=kernel_ms, steps=steps, phases=phases,
                     calib=calib, pipelined=pipelined)
