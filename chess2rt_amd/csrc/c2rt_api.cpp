@@ -57,6 +57,7 @@ struct c2rt_ctx {
     /* world-space corners of every node's padded bounding box (for the per-frame
      * screen rectangles); node_boxed[n] = 0: unbounded, never culled */
     uint32_t planes_only = 0;          /* every node is an axis plane (kNodeAxisPlane) */
+    uint32_t all_identity = 0;         /* every node has kNodeIdentityMatrix */
     int32_t ground_node = -1;          /* see RenderParams::ground_node */
     double ground_y = 0;
     double *shadow_rects = nullptr;    /* [kMaxCullNodes][4] */
@@ -373,6 +374,8 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
     p.tile_stats = ctx->tile_stats;
     p.row_group_start = 0;
     p.planes_only = ctx->planes_only;
+    static const bool no_idn = [] { const char *e = std::getenv("C2RT_NO_IDN"); return e && e[0] == '1'; }(); /* A/B: the general instances */
+    p.all_identity = no_idn ? 0u : ctx->all_identity;
     p.ground_node = ctx->ground_node;
     p.ground_y = ctx->ground_y;
     p.shadow_rects = ctx->shadow_rects;
@@ -897,6 +900,9 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         if (axis) d.flags |= kNodeAxisPlane;
         else ctx->planes_only = 0;
     }
+    ctx->all_identity = s->n_nodes > 0;
+    for (uint32_t n = 0; n < s->n_nodes; ++n)
+        if (!(nodes[n].flags & kNodeIdentityMatrix)) ctx->all_identity = 0;
 
     /* world-space bounding boxes of the nodes: object-space box (box_of), padded -> the 8
      * corners through Transform.point (affine: hull preserved) */

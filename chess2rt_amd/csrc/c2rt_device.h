@@ -188,6 +188,9 @@ struct RenderParams {
     /* every node is an "axis plane" (kNodeAxisPlane): the launcher picks the kernel instance that
      * decides plane misses from the un-normalised ray direction (plane_points_away) */
     uint32_t planes_only;
+    /* every node's matrix is the identity (translations allowed): the launcher picks the kSpecIdentity instances
+     * (c2rt_trace.inc) for uncounted frames with at most one light and no stereo */
+    uint32_t all_identity;
     /* "Ground plane" shadow culling (c2rt_api.cpp: ground_shadow_rects).  ground_node >= 0: node
      * ground_node is a Plane under an identity matrix with zero offset, at height ground_y.  In a
      * tile whose primary rays can reach that node only, every hit point lies on the plane inside the
