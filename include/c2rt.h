@@ -21,6 +21,15 @@
  *     (`imageio/image.d:18-54`).
  *   - one context per process and GPU; calls on a context are serialised by
  *     the caller (the reference has a single render thread).
+ *
+ * Environment (read once per process; measurement and test knobs, none of them
+ * changes a pixel): C2RT_EXACT=1 — every tile through the compiler's IEEE divide
+ * / sqrt (the round-2 arithmetic) instead of the shortened sequences;
+ * C2RT_NO_IDN=1 — the general kernel instances also for scenes whose node
+ * matrices are all the identity; C2RT_HOST_CHUNK_MB / C2RT_HOST_FIRST_FRAC /
+ * C2RT_HOST_COPY_STREAMS / C2RT_HOST_DIRECT_STORE — the host-output pipeline of
+ * c2rt_render_frame; C2RT_CSG_FIRST_CAP=<n> — test hook: first-pass CSG hit
+ * stacks of n entries (announced on stderr when set).
  */
 #ifndef C2RT_H
 #define C2RT_H
