@@ -83,6 +83,12 @@ extern (C) nothrow @nogc
     int c2rt_unpin_host_buffer(c2rt_ctx*, float* out_rgb);
     int c2rt_render_pixel(c2rt_ctx*, const c2rt_camera_frame*, const c2rt_render_opts*, int x, int y,
                           c2rt_trace_result*);
+    /// display words (Color.toRGB32, encoded in the render kernel) straight into `screen`'s uint twin: what
+    /// SDL2Gui.draw (gui/sdl2_gui.d:139-155) computes per pixel on the CPU today
+    int c2rt_render_frame_rgb32(c2rt_ctx*, const c2rt_camera_frame*, const c2rt_render_opts*, uint* out_rgb32,
+                                const shared(ubyte)* stop_flag);
+    /// tiles rendered a second time through the IEEE divide / sqrt path (a cost indicator; 0 on sane scenes)
+    int c2rt_get_exact_redos(c2rt_ctx*, ulong* outCount);
 }
 
 /// Owns the flat tables for one uploaded scene (GC memory; c2rt_upload_scene copies them).
