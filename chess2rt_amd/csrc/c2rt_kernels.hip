@@ -11,13 +11,19 @@
  *   - every lane walks the SAME node / geometry / light at the same time, so
  *     the scene records are read with scalar loads into SGPRs and the type
  *     dispatch is a scalar branch, never a divergent one;
- *   - CSG hit lists live in LDS, one [entry][lane] slab per nesting level
- *     (bank = lane, conflict-free for any per-lane entry index); only
- *     (dist, tag) is kept per hit and the winning hit is re-derived, which
- *     keeps the slab at 10 KiB per wave and level;
+ *   - CSG hit lists live in LDS, one per-lane stack per wave shared by the
+ *     nesting levels ([entry][lane]: bank = lane, conflict-free for any per-lane
+ *     entry index); only (dist, tag) is kept per hit and the winning hit is
+ *     re-derived: 10 KiB per wave at depth 1, 20 KiB at depth 4;
  *   - geometry is fp64 and colour fp32 in the reference's operation order
  *     (built with -ffp-contract=off), because checker edges, shadow
  *     terminators and CSG boundaries flip on 1-ulp differences.
+ *
+ * This file holds the kernel entry points and launchers.  The trace itself is
+ * c2rt_trace.inc, included twice below: lean:: (divide / sqrt / normalise through
+ * the shortened correctly rounded sequences of fp64_lean.h, optimistically) and
+ * exact:: (the compiler's IEEE expansions); render_one() runs a tile through
+ * lean:: and again through exact:: when an operand left the lean windows.
  *
  * What each function restates is cited as file:line of /root/reference/source.
  */

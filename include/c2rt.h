@@ -246,7 +246,12 @@ int c2rt_init(int device, c2rt_ctx **out);
  *     (peer access) — no gather buffer, no de-interleave pass;
  *   - c2rt_render_pixel and the strip / encode helpers run on the lead device.
  * C2RT_ERR_NO_DEVICE when a device id is out of range; C2RT_ERR_UNSUPPORTED
- * from c2rt_render_frame_device when a device cannot peer-map the lead. */
+ * from c2rt_render_frame_device when a device cannot peer-map the lead.
+ * EXPERIMENTAL on more than one PHYSICAL device: the GPU pool this was built
+ * on shows a job one GPU, so every test runs the slots on one device (ids
+ * repeated); peer access, cross-device events and the parallel copies have
+ * not executed across two GPUs yet.  A failing slot leaves the lead device
+ * current and the caller's stream ordered after every slot already launched. */
 int c2rt_init_multi(int device_count_or_0, const int *device_ids, c2rt_ctx **out);
 /* number of device slots of the context (1 for c2rt_init) */
 int c2rt_device_count(const c2rt_ctx *ctx);
