@@ -1049,7 +1049,7 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
  * variables exist for that measurement: C2RT_HOST_CHUNK_MB, C2RT_HOST_FIRST_FRAC, C2RT_HOST_COPY_STREAMS,
  * C2RT_HOST_DIRECT_STORE. */
 struct HostKnobs {
-    size_t chunk_bytes = 16u << 20; /* 4K float frame, ms: 2 MB 2.42, 4 MB 2.41, 8 MB 2.12, 16 MB 2.02, 24 MB 2.11, 32 MB 2.19 (copy alone: 1.75) */
+    size_t chunk_bytes = 13u << 20; /* 4K float frame (99.5 MB), ms by chunk count: 10 chunks 2.12, 9 2.04, 8 (this) 1.96, 7 1.98, 6 1.98, 5 2.02, 4 2.19 (copy alone: 1.75) */
     double first_frac = 1.0;        /* a smaller first chunk: no gain (the pipeline is copy-bound from the first copy on) */
     int copy_streams = 1;           /* two copy streams: no gain */
     /* kernel stores straight into the page-locked frame: 0 never, 1 the display-word frame (4 B/pixel: 1.30 ms
