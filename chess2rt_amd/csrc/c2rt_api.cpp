@@ -863,6 +863,25 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         for (int i = 0; i < 9; ++i) ident = ident && d.m[i] == I[i] && d.inv[i] == I[i] && d.tinv[i] == I[i];
         if (ident) d.flags |= kNodeIdentityMatrix;
         if (d.off[0] == 0 && d.off[1] == 0 && d.off[2] == 0) d.flags |= kNodeZeroOffset;
+        if (d.g.type == C2RT_GEOM_PLANE && !ident) {
+            /* hit_surface: normalized(mulvm((0, 1, 0), tinv)), operation for operation (this file is built
+             * without contraction; sqrt and division are IEEE on both sides) */
+            const double nx = 0.0, ny = 1.0, nz = 0.0;
+            const double *m = d.tinv;
+            const double vx = nx * m[0] + ny * m[3] + nz * m[6];
+            const double vy = nx * m[1] + ny * m[4] + nz * m[7];
+            const double vz = nx * m[2] + ny * m[5] + nz * m[8];
+            const double sq = vx * vx + vy * vy + vz * vz;
+            const double len = std::sqrt(sq);
+            const double inv = 1.0 / len;
+            const double wn[3] = {vx * inv, vy * inv, vz * inv};
+            if (std::isfinite(wn[0]) && std::isfinite(wn[1]) && std::isfinite(wn[2])) {
+                d.g.q[0] = wn[0];
+                d.g.q[1] = wn[1];
+                d.g.q[2] = wn[2];
+                d.flags |= kNodePlaneNormal;
+            }
+        }
         /* shading inputs of this node in one record */
         const DevShader &sh = shaders[d.shader];
         DevMat &m = d.mat;

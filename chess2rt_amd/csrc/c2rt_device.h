@@ -81,6 +81,10 @@ enum NodeFlags : uint32_t {
      * [1e-100, 1e100] and a positive y entry: the sign of the node-space direction's y follows from
      * the world-space direction's (plane_points_away, c2rt_kernels.hip) */
     kNodeAxisPlane = 4u,
+    /* a Plane under a non-identity matrix: DevNode::g.q[0..2] (unused by planes) hold the world normal
+     * normalize((0,1,0) * transposedInverse) — rt/node.d:41-43 — the same for every hit on the node, evaluated at
+     * upload with the reference's IEEE operations (finite results only) instead of per lane and per sample */
+    kNodePlaneNormal = 8u,
 };
 
 /* What shading a hit on a node reads, flattened at upload from

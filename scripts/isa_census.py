@@ -99,7 +99,9 @@ def main():
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags["FPFLAGS"].split() + \
           ["-fhip-fp32-correctly-rounded-divide-sqrt"] + flags["KERNELFLAGS"].split() + \
           ["-DC2RT_UNIT=%s" % unit, "-gline-tables-only", "--offload-device-only", "-S", SRC, "-o", out, "-I" + os.path.join(ROOT, "include")]
-    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(SRC):
+    csrc = os.path.dirname(SRC)
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith(('.hip', '.inc', '.h')))
+    if not os.path.exists(out) or os.path.getmtime(out) < newest:
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     spans = {"c2rt_kernels.hip": function_spans(SRC), "c2rt_trace.inc": function_spans(TRACE)}
 
