@@ -196,8 +196,8 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     extern __shared__ __align__(16) char lds[];
     if (threadIdx.x != 0) return;
     Ctx cx;
-    cx.geoms = P.geoms;
-    cx.nodes = P.nodes;
+    cx.geoms = (GeomP)P.geoms;
+    cx.nodes = (NodeP)P.nodes;
     cx.n_nodes = P.n_nodes;
     cx.kargs = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     cx.lds = lds;
