@@ -71,6 +71,8 @@ struct c2rt_ctx {
     c2rt_trace_result *probe = nullptr;
     uint8_t *srgb_lut = nullptr;   /* [4097] */
     uint32_t *retry_list = nullptr; /* RenderParams::retry_list: [0] count, then tile (block) indices */
+    uint32_t *tile_masks = nullptr; /* RenderParams::tile_masks: 4 words per (block, wave) of the current launch */
+    size_t tile_mask_entries = 0;
     uint32_t *tile_stats = nullptr; /* diagnostics (c2rt_debug_set_tile_stats): caller-owned device buffer */
     size_t retry_words = 0;
     bool counters_valid = false;
@@ -535,6 +537,21 @@ int launch_frame(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStre
     if (levels == 0) p.csg_cap = 0;
     p.retry_mode = 0;
     p.redo_counter = ctx->counters + 3;
+    /* the tiles' culling masks, by the pre-pass kernel, in front of the frame kernel on the same stream (frames
+     * of one context are ordered across streams: one table per context) */
+    p.tile_masks = nullptr;
+    if (p.n_cull && !v.dof_or_stereo) {
+        const size_t entries = tile_mask_entries(p);
+        if (entries > ctx->tile_mask_entries) {
+            if (ctx->tile_masks) { (void)hipFree(ctx->tile_masks); ctx->tile_masks = nullptr; ctx->tile_mask_entries = 0; }
+            const hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->tile_masks), entries * 4 * sizeof(uint32_t));
+            if (e != hipSuccess) return (int)e;
+            ctx->tile_mask_entries = entries;
+        }
+        p.tile_masks = ctx->tile_masks;
+        const int e = launch_tile_masks(p, ctx->tile_masks, stream);
+        if (e != 0) return e;
+    }
     if (levels < 2) return launch_render(p, v, stream);
     const size_t blocks = (size_t)p.blocks_x * ((p.tiles_y + 7u) / 8u * 8u);
     if (blocks + 1 > ctx->retry_words) {
@@ -700,7 +717,7 @@ void c2rt_destroy(c2rt_ctx *ctx)
         if (e) (void)hipEventDestroy(e);
     for (const auto &pb : ctx->pinned) (void)hipHostUnregister(pb.first);
     void *bufs[] = {ctx->geoms, ctx->nodes, ctx->shaders, ctx->textures, ctx->lights, ctx->texels,
-                    ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut, ctx->shadow_rects, ctx->retry_list};
+                    ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut, ctx->shadow_rects, ctx->retry_list, ctx->tile_masks};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete ctx;

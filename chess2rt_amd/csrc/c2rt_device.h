@@ -214,6 +214,10 @@ struct RenderParams {
     uint32_t csg_cap;
     uint32_t retry_mode, retry_max;
     uint32_t *retry_list;
+    /* per (block, wave) of this launch: {primary mask, shadow mask of light 0, ground bits, 0} — written by the
+     * pre-pass kernel (launch_tile_masks, c2rt_trace.inc: tile_mask_entry) in front of every launch with
+     * n_cull != 0, read by the frame kernel with one scalar load per tile */
+    const uint32_t *tile_masks;
     /* diagnostics build only (make VARIANT=tilestats EXTRA_HIPFLAGS=-DC2RT_TILE_STATS=1, scripts/tile_stats.py):
      * per tile {shader-clock cycles the wave spent on it, class bits}; never read by the product build */
     uint32_t *tile_stats;
@@ -250,6 +254,9 @@ template <> int launch_render_level<3>(const RenderParams &, bool, void *);
 template <> int launch_render_level<4>(const RenderParams &, bool, void *);
 int launch_render(const RenderParams &p, const KernelVariant &v, void *stream);
 int launch_probe(const RenderParams &p, const KernelVariant &v, void *stream);
+/* entries of RenderParams::tile_masks a launch of `p` reads (4 words each); the pre-pass that fills them */
+size_t tile_mask_entries(const RenderParams &p);
+int launch_tile_masks(const RenderParams &p, uint32_t *table, void *stream);
 int launch_deinterleave(const float *gathered, float *frame, uint32_t width, uint32_t height,
                         uint32_t strip_height, uint32_t world, uint32_t rows_pad, uint32_t words_per_pixel, void *stream);
 int launch_encode_rgb32(const float *frame, uint32_t *out, uint64_t n_pixels,
