@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) tile_masks_kernel(const RenderParams P, u
     typedef uint32_t __attribute__((ext_vector_type(4))) u4_t;
     u4_t v;
     v.x = m[0]; v.y = m[1]; v.z = m[2]; v.w = m[3];
-    reinterpret_cast<u4_t *>(table)[i] = v;
+    reinterpret_cast<u4_t *>(table)[exact::tile_mask_slot(P, i / kWavesPerBlock, i % kWavesPerBlock)] = v;
 }
 #endif /* C2RT_UNIT == 5 */
 

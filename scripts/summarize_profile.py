@@ -16,7 +16,12 @@ with open(os.path.join(src, "trace", "trace_kernel_stats.csv")) as f:
     rows = list(csv.DictReader(f))
 summ["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows]
 with open(os.path.join(src, "trace", "trace_kernel_trace.csv")) as f:
-    tr_all = [r for r in csv.DictReader(f) if KERNEL in r["Kernel_Name"]]
+    all_rows = list(csv.DictReader(f))
+tr_all = [r for r in all_rows if KERNEL in r["Kernel_Name"]]
+# the per-tile culling masks are written by a pre-pass kernel in front of every frame launch (one lane per tile)
+pre = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in all_rows if "tile_masks_kernel" in r["Kernel_Name"]][-20:]
+if pre:
+    summ["tile_masks_prepass_avg_duration_us_timed"] = statistics.mean(pre) / 1e3
 # Nested-CSG scenes launch the frame kernel twice per frame: the whole grid with the reduced hit stack,
 # then a fixed 2048-workgroup grid over the tiles that overflowed it (usually none).  The frame launch
 # is the one with the larger grid; the retry launches are reported beside it.
