@@ -71,7 +71,7 @@ struct c2rt_ctx {
     c2rt_trace_result *probe = nullptr;
     uint8_t *srgb_lut = nullptr;   /* [4097] */
     uint32_t *retry_list = nullptr; /* RenderParams::retry_list: [0] count, then tile (block) indices */
-    uint32_t *tile_masks = nullptr; /* RenderParams::tile_masks: 4 words per (block, wave) of the current launch */
+    uint32_t *tile_masks = nullptr; /* RenderParams::tile_masks: 4 words per tile of the current frame's local rows */
     size_t tile_mask_entries = 0;
     uint32_t *tile_stats = nullptr; /* diagnostics (c2rt_debug_set_tile_stats): caller-owned device buffer */
     size_t retry_words = 0;
@@ -516,6 +516,27 @@ KernelVariant variant_of(const c2rt_ctx *ctx, const c2rt_camera_frame *cam)
     return v;
 }
 
+/* The tiles' culling masks for the local rows [p.row_offset, p.row_offset + p.local_rows), by the pre-pass kernel,
+ * in front of the frame kernel on the same stream (frames of one context are ordered across streams: one table
+ * per context).  Sets p.tile_masks / mask_row0 / mask_rows; a no-op for frames without culling rectangles.
+ * Returns a hipError_t. */
+int prepare_tile_masks(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStream_t stream)
+{
+    p.tile_masks = nullptr;
+    p.mask_row0 = p.row_offset;
+    p.mask_rows = p.local_rows;
+    if (!p.n_cull || v.dof_or_stereo || !p.local_rows) return 0;
+    const size_t entries = tile_mask_entries(p);
+    if (entries > ctx->tile_mask_entries) {
+        if (ctx->tile_masks) { (void)hipFree(ctx->tile_masks); ctx->tile_masks = nullptr; ctx->tile_mask_entries = 0; }
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->tile_masks), entries * 4 * sizeof(uint32_t));
+        if (e != hipSuccess) return (int)e;
+        ctx->tile_mask_entries = entries;
+    }
+    p.tile_masks = ctx->tile_masks;
+    return launch_tile_masks(p, ctx->tile_masks, stream);
+}
+
 /* One frame launch.  Scenes with nested CsgOps (depth >= 2) run the kernel with a reduced hit-stack
  * capacity (two waves per SIMD instead of one at depth 4) and then, on the same stream, the
  * full-capacity relaunch over the tiles that overflowed it — none, for trees whose primitives yield
@@ -537,19 +558,8 @@ int launch_frame(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStre
     if (levels == 0) p.csg_cap = 0;
     p.retry_mode = 0;
     p.redo_counter = ctx->counters + 3;
-    /* the tiles' culling masks, by the pre-pass kernel, in front of the frame kernel on the same stream (frames
-     * of one context are ordered across streams: one table per context) */
-    p.tile_masks = nullptr;
-    if (p.n_cull && !v.dof_or_stereo) {
-        const size_t entries = tile_mask_entries(p);
-        if (entries > ctx->tile_mask_entries) {
-            if (ctx->tile_masks) { (void)hipFree(ctx->tile_masks); ctx->tile_masks = nullptr; ctx->tile_mask_entries = 0; }
-            const hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->tile_masks), entries * 4 * sizeof(uint32_t));
-            if (e != hipSuccess) return (int)e;
-            ctx->tile_mask_entries = entries;
-        }
-        p.tile_masks = ctx->tile_masks;
-        const int e = launch_tile_masks(p, ctx->tile_masks, stream);
+    if (!p.tile_masks) { /* (a chunked frame has prepared its table already: render_to_host) */
+        const int e = prepare_tile_masks(ctx, p, v, stream);
         if (e != 0) return e;
     }
     if (levels < 2) return launch_render(p, v, stream);
@@ -1180,6 +1190,10 @@ static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2r
     }
     bool cancelled = false;
     int n_chunks = 0;
+    { /* one mask table for the whole frame: every chunk's launch reads its rows of it */
+        const int e = prepare_tile_masks(ctx, p, variant, ctx->stream);
+        if (e != 0) return fail(ctx, C2RT_ERR_HIP, "tile-mask pre-pass launch: %s", hipGetErrorString((hipError_t)e));
+    }
     for (uint32_t off = 0; off < rows && n_chunks < kMaxChunks; ++n_chunks) {
         if (stop_flag && *stop_flag) { cancelled = true; break; }
         uint32_t n = n_chunks == 0 ? first : chunk;

@@ -214,10 +214,12 @@ struct RenderParams {
     uint32_t csg_cap;
     uint32_t retry_mode, retry_max;
     uint32_t *retry_list;
-    /* per (block, wave) of this launch: {primary mask, shadow mask of light 0, ground bits, 0} — written by the
-     * pre-pass kernel (launch_tile_masks, c2rt_trace.inc: tile_mask_entry) in front of every launch with
-     * n_cull != 0, read by the frame kernel with one scalar load per tile */
+    /* per tile: {primary mask, shadow mask of light 0, ground bits, 0} — written by the pre-pass kernel
+     * (launch_tile_masks, c2rt_trace.inc: tile_mask_entry) once per frame with n_cull != 0, read by the frame
+     * kernel with one scalar load per tile.  The table covers the local rows [mask_row0, mask_row0 + mask_rows)
+     * (mask_row0 a multiple of the tile height): the launches of a chunked host-output frame share one table */
     const uint32_t *tile_masks;
+    uint32_t mask_row0, mask_rows;
     /* diagnostics build only (make VARIANT=tilestats EXTRA_HIPFLAGS=-DC2RT_TILE_STATS=1, scripts/tile_stats.py):
      * per tile {shader-clock cycles the wave spent on it, class bits}; never read by the product build */
     uint32_t *tile_stats;

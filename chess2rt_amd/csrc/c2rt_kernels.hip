@@ -260,19 +260,21 @@ __global__ void encode_rgb32_kernel(const float *__restrict__ frame, uint32_t *_
     }
 }
 
-/* The culling masks of every tile of a launch, one lane per tile (c2rt_trace.inc: tile_mask_entry): entry
- * (block b, wave w) at 4 * (b * kWavesPerBlock + w).  Runs in front of every frame-kernel launch whose frame has
- * culling rectangles, on the same stream. */
-__global__ void __launch_bounds__(256) tile_masks_kernel(const RenderParams P, uint32_t *__restrict__ table, uint32_t entries)
+/* The culling masks of every tile of a frame's local rows, one lane per tile (c2rt_trace.inc: tile_mask_entry,
+ * tile_mask_slot).  Runs once per frame whose camera leaves culling rectangles, in front of the frame kernel's
+ * launch(es), on the same stream. */
+__global__ void __launch_bounds__(256) tile_masks_kernel(const RenderParams P, uint32_t *__restrict__ table, uint32_t tile_rows)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= entries) return;
+    const uint32_t cols = P.blocks_x * kWavesPerBlock;
+    const uint32_t trow = i / cols, tcol = i % cols;
+    if (trow >= tile_rows) return;
     uint32_t m[4];
-    exact::tile_mask_entry(P, (exact::KArgs)__builtin_amdgcn_kernarg_segment_ptr(), i / kWavesPerBlock, i % kWavesPerBlock, m);
+    exact::tile_mask_entry(P, (exact::KArgs)__builtin_amdgcn_kernarg_segment_ptr(), trow, tcol, m);
     typedef uint32_t __attribute__((ext_vector_type(4))) u4_t;
     u4_t v;
     v.x = m[0]; v.y = m[1]; v.z = m[2]; v.w = m[3];
-    reinterpret_cast<u4_t *>(table)[exact::tile_mask_slot(P, i / kWavesPerBlock, i % kWavesPerBlock)] = v;
+    reinterpret_cast<u4_t *>(table)[exact::tile_mask_slot(P, trow, tcol)] = v;
 }
 #endif /* C2RT_UNIT == 5 */
 
@@ -351,19 +353,16 @@ int launch_render(const RenderParams &p, const KernelVariant &v, void *stream)
 
 size_t tile_mask_entries(const RenderParams &p)
 {
-#if C2RT_XCD_SWIZZLE
-    const uint32_t tiles_y_pad = (p.tiles_y + 7u) / 8u * 8u;
-#else
-    const uint32_t tiles_y_pad = p.tiles_y;
-#endif
-    return (size_t)p.blocks_x * tiles_y_pad * kWavesPerBlock;
+    const uint32_t tile_rows = (p.mask_rows + kTileH - 1) / kTileH;
+    return (size_t)((tile_rows + 7u) / 8u * 8u) * p.blocks_x * kWavesPerBlock;
 }
 
 int launch_tile_masks(const RenderParams &p, uint32_t *table, void *stream)
 {
-    const uint32_t entries = (uint32_t)tile_mask_entries(p);
-    if (!entries) return 0;
-    hipLaunchKernelGGL(tile_masks_kernel, dim3((entries + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), p, table, entries);
+    const uint32_t tile_rows = (p.mask_rows + kTileH - 1) / kTileH;
+    const uint32_t lanes = tile_rows * p.blocks_x * kWavesPerBlock;
+    if (!lanes) return 0;
+    hipLaunchKernelGGL(tile_masks_kernel, dim3((lanes + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), p, table, tile_rows);
     return (int)hipGetLastError();
 }
 
