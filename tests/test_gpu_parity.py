@@ -401,6 +401,30 @@ def test_host_output_chunks_pinned_buffer_and_midframe_cancel(gpu_ctx):
     assert gpu_ctx.rayStats() == (st["primary"], st["shadow"])
 
 
+def test_chunks_of_a_pinned_4k_frame_share_one_mask_table(gpu_ctx, scenes_dir):
+    """A 4K float frame into a pinned buffer is rendered in row chunks (several launches of the frame kernel,
+    each streaming back while the next renders) that read ONE per-tile mask table written by one pre-pass launch;
+    a pageable buffer gets the frame from a single launch.  Same bits — whole frame and the strips of rank 1 of 2
+    (chunks of interleaved strips: the table's rows are local rows)."""
+    scene = c2.parseSceneFromFile(os.path.join(scenes_dir, "lecture5.sdl"))
+    scene.setFrameSize(3840, 2160)
+    scene.setAA(False)
+    cam = scene.beginFrame()
+    gpu_ctx.uploadScene(scene.desc)
+    for kw in ({}, dict(strip_height=8, strip_rank=1, strip_world=2)):
+        opts = scene.renderOpts(**kw)
+        rows = gpu_ctx.localRows(opts)
+        one_launch = gpu_ctx.renderFrame(cam, opts)
+        assert one_launch.shape[0] == rows
+        out = np.full((rows, opts.width, 3), -1.0, np.float32)
+        gpu_ctx.pinHostBuffer(out)
+        try:
+            gpu_ctx.renderFrameInto(cam, opts, out)
+            assert np.array_equal(out.view(np.uint32), one_launch.view(np.uint32))
+        finally:
+            gpu_ctx.unpinHostBuffer(out)
+
+
 def test_random_scene_fuzz(gpu_ctx, tmp_path, scenes_dir):
     """120 seeded random scenes (CSG trees up to depth 3-4 incl. planes as operands and Op(a, a), scaled /
     'rotated' / translated nodes, 1-3 lights, every shader and texture type): GPU == oracle within 1e-4,
