@@ -39,10 +39,12 @@ constexpr int kBlockThreads = kWave * kWavesPerBlock;
 constexpr int kCsgLdsPerEntry = kWave * (8 + 2);
 /* a CsgOp's list holds at most 8 + 8 entries and lists nest: depth x 16 entries can never overflow */
 constexpr int kCsgFullCap(int levels) { return kCsgEntries * (levels > 0 ? levels : 1); }
-/* first-pass capacity per nesting depth (10 / 10 / 15 / 20 KiB per wave): what non-pathological trees
- * need with margin (two hits per primitive child = 4 entries per level); tiles that overflow are
- * rendered again at kCsgFullCap */
-constexpr int kCsgFirstCap(int levels) { return levels <= 1 ? 16 : (levels == 2 ? 16 : (levels == 3 ? 24 : 32)); }
+/* first-pass capacity per nesting depth (10 / 10 / 12.5 / 12.5 KiB per wave): what non-pathological trees
+ * need (two hits per primitive child = 4 entries per level) with a margin, and no more than lets THREE
+ * workgroups of four waves share a CU's 160 KiB (the nested instances run three waves per SIMD, c2rt_kernels.hip:
+ * occ_of); tiles that overflow are rendered again at kCsgFullCap */
+constexpr int kCsgFirstCap(int levels) { return levels <= 2 ? 16 : 20; }
+static_assert(3 * kWavesPerBlock * kCsgFirstCap(C2RT_MAX_CSG_DEPTH) * kCsgLdsPerEntry <= 160 * 1024, "three workgroups per CU");
 
 enum GeomFlags : int32_t {
     kGeomBounded = 1,              /* `bound` is valid: a ray that misses it cannot hit */

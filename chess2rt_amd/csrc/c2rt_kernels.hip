@@ -68,13 +68,23 @@ __device__ __noinline__ UV c2_sphere_uv(double dx, double dz, double w)
  *   depth 1, at most one light: 4 waves — 128 VGPRs since the cube / sphere face tables moved to the upload
  *     and the hit's lighting terms are evaluated before the shadow test (was 149 at 3 waves);
  *   depth 1, several lights (the hit stays live across the light loop) and depth-1 DOF: 3 waves (144-162);
- *   depth 2: 2 waves (176-202); depth 3 / 4: 2 waves (253-256, depth 4 spills ~45 VGPRs: measured faster
- *     than 1 wave without spills, 19.8 -> 12 ms on csg_stress). */
+ *   depth 2 / 3 / 4: THREE waves (168 VGPRs) although they then spill (depth 4 multi-light: 136 VGPRs, 240 B of
+ *     scratch per lane; at two waves it needs 230 and spills none): a wave of these instances issues one
+ *     instruction at a time and a third of its instructions are scalar, so with two waves per SIMD the VALU idles
+ *     half the time (VALU busy 0.53) — the third wave is worth more than the spills cost: csg_stress.sdl cut to
+ *     depth 2 / 3 / 4: 2.33 -> 1.88, 4.60 -> 3.97, 10.21 -> 8.53 ms (scripts/depth_occupancy.sh; four waves:
+ *     2.59 / 5.48 / 10.5).  The hit stacks have to fit three workgroups per CU too: kCsgFirstCap, c2rt_device.h. */
 #ifndef C2RT_OCC_U1
 #define C2RT_OCC_U1 4
 #endif
 #ifndef C2RT_OCC_DEEP
-#define C2RT_OCC_DEEP 2
+#define C2RT_OCC_DEEP 3
+#endif
+#ifndef C2RT_OCC_U2
+#define C2RT_OCC_U2 3
+#endif
+#ifndef C2RT_OCC_U3
+#define C2RT_OCC_U3 C2RT_OCC_DEEP
 #endif
 template <int LEVELS, int DOF, bool MLC>
 constexpr int occ_of()
@@ -82,7 +92,7 @@ constexpr int occ_of()
 #ifndef C2RT_OCC_U0
 #define C2RT_OCC_U0 4
 #endif
-    return LEVELS == 0 ? (DOF ? 4 : C2RT_OCC_U0) : (LEVELS == 1 ? ((DOF || MLC) ? 3 : C2RT_OCC_U1) : (LEVELS == 2 ? 2 : C2RT_OCC_DEEP));
+    return LEVELS == 0 ? (DOF ? 4 : C2RT_OCC_U0) : (LEVELS == 1 ? ((DOF || MLC) ? 3 : C2RT_OCC_U1) : (LEVELS == 2 ? C2RT_OCC_U2 : (LEVELS == 3 ? C2RT_OCC_U3 : C2RT_OCC_DEEP)));
 }
 #define C2RT_OCC_OF(L, D, M) __attribute__((amdgpu_waves_per_eu(occ_of<L, D, M>(), occ_of<L, D, M>())))
 #ifndef C2RT_TILE_STATS
