@@ -114,10 +114,9 @@ constexpr bool kLean = false;
 #ifndef C2RT_LEAN
 #define C2RT_LEAN 1 /* 0: the production instances run exact:: only (A/B builds) */
 #endif
-/* The deepest CSG nesting whose instances carry the lean:: copy.  Depth 4 does not: at two waves per SIMD it is
- * bound by latency, not by VALU issue (lean:: 10.39 ms against 10.42 on csg_stress), and with both copies in one
- * kernel it spilled 21 VGPRs (96 B of scratch per lane, 1.4 GB of scratch writes per frame) where exact:: alone
- * fits its 256 registers with none. */
+/* The deepest CSG nesting whose instances carry the lean:: copy.  Depth 4 does not: measured with and without it
+ * at two waves per SIMD (10.39 / 10.42 ms on csg_stress) and at three (8.60 / 8.56) — no difference, twice the
+ * code. */
 #ifndef C2RT_LEAN_MAX_LEVELS
 #define C2RT_LEAN_MAX_LEVELS 3
 #endif
