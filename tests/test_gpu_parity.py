@@ -513,6 +513,45 @@ def test_prepass_only_preview(gpu_ctx, tmp_path):
     assert flag[0] == 0 and (out == 7.0).all()
 
 
+def test_csg_children_with_coincident_surfaces_match_the_oracle(gpu_ctx, tmp_path):
+    """Depth-1 CsgOps whose children share surfaces, so that hit lists hold EQUAL distances (ties), odd counts
+    (eye inside a child) and tangent contacts: the regular case of the device's CsgOp (0 or 2 hits per child, all
+    distances distinct, decided by comparisons) must hand exactly these rays to the literal shell sort and walk —
+    whose order of equal keys and leaf-identity toggles decide the pixel.  Bit-equal to the oracle."""
+    prims = """Cube "a" { center 0 50 200; side 100 }
+               Cube "b" { center 50 50 200; side 100 }        // shares the y and z face planes of "a"
+               Cube "c" { center 0 50 200; side 60 }          // concentric, inside "a"
+               Sphere "t" { center 0 50 200; R 50 }           // tangent to the faces of "a" from inside
+               Sphere "o" { center 0 50 150; R 50 }           // pokes through the front face
+               Cube "e" { center 0 165 0; side 40 }           // the eye sits at its centre
+               Plane "f" { y 0 }"""
+    ops = [("CsgUnion", "a", "b"), ("CsgInter", "a", "b"), ("CsgDiff", "a", "b"), ("CsgDiff", "b", "a"),
+           ("CsgDiff", "a", "c"), ("CsgInter", "a", "t"), ("CsgDiff", "a", "t"), ("CsgUnion", "t", "a"),
+           ("CsgDiff", "a", "o"), ("CsgInter", "o", "a"), ("CsgUnion", "e", "a"), ("CsgDiff", "a", "a"),
+           ("CsgInter", "t", "t")]
+    for i, (op, l, r) in enumerate(ops):
+        text = """Scene { GlobalSettings { ambientLightColor 0.1 0.1 0.1 }
+            Camera { pos 0 165 0; pitch -30; fov 90 }
+            Lights { PointLight "k" { pos -90 700 350; color 1 1 1; power 800000 } }
+            Geometries { %s
+               %s "x" { left "%s"; right "%s" } }
+            Shaders { Phong "p" { color 0.5 0.5 0; exponent 60 }; Lambert "l" { color 0.7 0.7 0.7 } }
+            Nodes { Node "floor" { geometry "f"; shader "l" }; Node "n" { geometry "x"; shader "p" } } }""" % (prims, op, l, r)
+        scene = _load_text(tmp_path, text, "coincident%d.sdl" % i)
+        scene.setFrameSize(320, 200)
+        for aa in (False, True):
+            scene.setAA(aa)
+            cam = scene.beginFrame()
+            opts = scene.renderOpts(count_rays=1)
+            gpu_ctx.uploadScene(scene.desc)
+            a = gpu_ctx.renderFrame(cam, opts)
+            st = {}
+            ref = orc.render_frame(scene.desc, cam, opts, 2, st)
+            assert np.array_equal(np.isnan(a), np.isnan(ref)), (op, l, r)
+            assert np.array_equal(a.view(np.uint32), ref.view(np.uint32)), (op, l, r, maxdiff(a, ref))
+            assert gpu_ctx.rayStats() == (st["primary"], st["shadow"]), (op, l, r)
+
+
 def test_pathological_scenes_terminate_and_match(gpu_ctx, tmp_path):
     """Inputs on which the reference itself never terminates (findAllIntersections loops for ever when
     `p + dir*1e-6 == p` or the hit is NaN) or degenerates (NaN camera, zero-size primitives): the device
