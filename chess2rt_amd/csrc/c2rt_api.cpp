@@ -221,7 +221,16 @@ BoxInfo box_of(const c2rt_scene_desc *s, int32_t g, std::vector<BoxInfo> &memo, 
         for (int i = 0; i < 3; ++i) { b.lo[i] = p[i] - e; b.hi[i] = p[i] + e; }
     } else if (is_csg(t)) {
         const BoxInfo bl = box_of(s, s->geom_child[2 * g], memo, geoms), br = box_of(s, s->geom_child[2 * g + 1], memo, geoms);
-        if ((geoms[g].flags & kCsgShortA) && bl.bounded) {
+        /* Where can a HIT of this CsgOp lie?  On a leaf's surface of either subtree, in general: the union.  Inside
+         * the left child's box only when the walk's `inL` really means "inside the left child": the left child is a
+         * PRIMITIVE (its entries carry its own identity, so they and only they toggle inL — kCsgShortA excludes the
+         * same leaf inside the right subtree) and the operator needs inL (Inter / Diff).  With a CsgOp as left child
+         * no entry ever equals `left` (rt/geometry.d:314-317 compares the LEAF): inL is the parity of the left
+         * list for the whole walk, and an Inter / Diff can come out "in" at an entry of the RIGHT child far outside
+         * the left child's box — e.g. a shadow ray whose left hits lie beyond the light, occluded by a right-child
+         * surface in front of it.  (Found by the offline sweep, seed 108921: three pixels of a 64x48 frame lost a
+         * shadow to the view-pyramid culling of shadow rays, which asks where the occluder can BE.) */
+        if ((geoms[g].flags & kCsgShortA) && bl.bounded && !is_csg(s->geom_type[s->geom_child[2 * g]])) {
             b = bl;
         } else if (bl.bounded && br.bounded) {
             b.bounded = true;
@@ -409,6 +418,18 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
             for (uint32_t l = 0; l < p.n_cull_lights; ++l) light_side_of(cam, &ctx->light_pos[3 * (size_t)l], p.light_side[l]);
         }
     }
+    /* diagnostics hook (like C2RT_CSG_FIRST_CAP; frames are unchanged by construction, slower): C2RT_DEBUG_CULL bit 0:
+     * no culling rectangles at all; bit 1: no ground-plane refinement of the shadow mask; bit 2: no view-pyramid
+     * culling of shadow rays */
+    static const int debug_cull = [] {
+        const char *e = std::getenv("C2RT_DEBUG_CULL");
+        const int v = e ? std::atoi(e) : 0;
+        if (v) std::fprintf(stderr, "libc2rt: diagnostics hook C2RT_DEBUG_CULL=%d is active (culling partly disabled; frames are unchanged, slower)\n", v);
+        return v;
+    }();
+    if (debug_cull & 1) p.n_cull = 0;
+    if (debug_cull & 2) p.ground_node = -1;
+    if (debug_cull & 4) p.n_cull_lights = 0;
 }
 
 /* Screen rectangle of a node for this frame: the projection of the 8 world-space

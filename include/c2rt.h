@@ -29,7 +29,9 @@
  * matrices are all the identity; C2RT_HOST_CHUNK_MB / C2RT_HOST_FIRST_FRAC /
  * C2RT_HOST_COPY_STREAMS / C2RT_HOST_DIRECT_STORE — the host-output pipeline of
  * c2rt_render_frame; C2RT_CSG_FIRST_CAP=<n> — test hook: first-pass CSG hit
- * stacks of n entries (announced on stderr when set).
+ * stacks of n entries; C2RT_DEBUG_CULL=<bits> — diagnostics hook: 1 no culling
+ * rectangles, 2 no ground-plane refinement of the shadow mask, 4 no
+ * view-pyramid culling of shadow rays (both announced on stderr when set).
  */
 #ifndef C2RT_H
 #define C2RT_H

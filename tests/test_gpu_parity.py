@@ -552,6 +552,32 @@ def test_csg_children_with_coincident_surfaces_match_the_oracle(gpu_ctx, tmp_pat
             assert gpu_ctx.rayStats() == (st["primary"], st["shadow"]), (op, l, r)
 
 
+def test_occluder_outside_the_left_childs_box(gpu_ctx, tmp_path, scenes_dir):
+    """Scene 108921 of the offline sweep (scripts/fuzz_big.py): Diff / Inter nodes whose LEFT child is a CsgOp.  The
+    reference's walk compares leaves with `left` (rt/geometry.d:314-317), so no entry ever toggles inL there: inL is
+    the parity of the left list, and the operator can come out "in" at an entry of the RIGHT child anywhere along the
+    ray — outside the left child's box.  Three floor pixels lost a shadow to the view-pyramid culling of shadow rays
+    while the culling boxes of such nodes were their left child's box (c2rt_api.cpp: box_of)."""
+    import shutil
+    from scene_fuzz import random_scene_sdl
+
+    shutil.copy(os.path.join(scenes_dir, "floor.bmp"), tmp_path / "floor.bmp")
+    path = tmp_path / "fuzz108921.sdl"
+    path.write_text(random_scene_sdl(108921, max_depth=4))
+    scene = c2.parseSceneFromFile(str(path))
+    for w, h in ((64, 48), (256, 192)):
+        scene.setFrameSize(w, h)
+        cam = scene.beginFrame()
+        opts = scene.renderOpts(count_rays=1)
+        gpu_ctx.uploadScene(scene.desc)
+        a = gpu_ctx.renderFrame(cam, opts)
+        st = {}
+        ref = orc.render_frame(scene.desc, cam, opts, 2, st)
+        assert np.array_equal(np.isnan(a), np.isnan(ref))
+        assert np.array_equal(a.view(np.uint32), ref.view(np.uint32)), maxdiff(a, ref)
+        assert gpu_ctx.rayStats() == (st["primary"], st["shadow"])
+
+
 def test_pathological_scenes_terminate_and_match(gpu_ctx, tmp_path):
     """Inputs on which the reference itself never terminates (findAllIntersections loops for ever when
     `p + dir*1e-6 == p` or the hit is NaN) or degenerates (NaN camera, zero-size primitives): the device
