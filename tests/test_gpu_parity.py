@@ -552,6 +552,34 @@ def test_csg_children_with_coincident_surfaces_match_the_oracle(gpu_ctx, tmp_pat
             assert gpu_ctx.rayStats() == (st["primary"], st["shadow"]), (op, l, r)
 
 
+def test_random_scene_sweep(gpu_ctx, tmp_path, scenes_dir):
+    """3 000 more seeded random scenes at 64x48 (the generators of the offline sweeps, scripts/fuzz_big.py: general
+    scenes with CSG trees to depth 4 and many-lights scenes; ~15 s): every float of every frame equal to the
+    oracle's, same NaN pattern, same ray counts — through the production and the counting instances (conftest)."""
+    import shutil
+    from scene_fuzz import many_lights_scene_sdl, random_scene_sdl
+
+    shutil.copy(os.path.join(scenes_dir, "floor.bmp"), tmp_path / "floor.bmp")
+    path = tmp_path / "sweep.sdl"
+    differing = 0
+    for seed in range(200000, 203000):
+        path.write_text(many_lights_scene_sdl(seed) if seed % 5 == 0 else random_scene_sdl(seed, max_depth=4 if seed % 2 else 3))
+        scene = c2.parseSceneFromFile(str(path))
+        scene.setFrameSize(64, 48)
+        cam = scene.beginFrame()
+        opts = scene.renderOpts(count_rays=1)
+        gpu_ctx.uploadScene(scene.desc)
+        a = gpu_ctx.renderFrame(cam, opts)
+        st = {}
+        ref = orc.render_frame(scene.desc, cam, opts, 8, st)
+        both_nan = np.isnan(a) & np.isnan(ref)
+        assert np.array_equal(np.isnan(a), np.isnan(ref)), seed
+        differing += int(((a.view(np.uint32) != ref.view(np.uint32)) & ~both_nan).sum())
+        assert maxdiff(a, ref)[0] <= TOL, seed
+        assert gpu_ctx.rayStats() == (st["primary"], st["shadow"]), seed
+    assert differing == 0
+
+
 def test_occluder_outside_the_left_childs_box(gpu_ctx, tmp_path, scenes_dir):
     """Scene 108921 of the offline sweep (scripts/fuzz_big.py): Diff / Inter nodes whose LEFT child is a CsgOp.  The
     reference's walk compares leaves with `left` (rt/geometry.d:314-317), so no entry ever toggles inL there: inL is
