@@ -25,9 +25,10 @@ ctx = BothContext(0); worst=0; bad=0; nne=0
 from scene_fuzz import many_lights_scene_sdl
 START = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 COUNT = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (64, 48)   # frame size: more tiles, other culling rectangles
 for seed in range(START, START + COUNT):
     open(d+"/f.sdl","w").write(many_lights_scene_sdl(seed) if seed % 5 == 0 else random_scene_sdl(seed, max_depth=4 if seed%2 else 3))
-    s=c2.parseSceneFromFile(d+'/f.sdl'); s.setFrameSize(64,48); cam=s.beginFrame(); opts=s.renderOpts(count_rays=1)
+    s=c2.parseSceneFromFile(d+'/f.sdl'); s.setFrameSize(W,H); cam=s.beginFrame(); opts=s.renderOpts(count_rays=1)
     ctx.uploadScene(s.desc); a=ctx.renderFrame(cam,opts); pr,sh=ctx.rayStats(); st={}
     r=orc.render_frame(s.desc,cam,opts,8,st)
     dd=np.abs(a.astype(np.float64)-r.astype(np.float64)); dd=np.where(np.isnan(a)&np.isnan(r),0,dd)
