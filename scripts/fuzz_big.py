@@ -33,6 +33,7 @@ for seed in range(START, START + COUNT):
     r=orc.render_frame(s.desc,cam,opts,8,st)
     dd=np.abs(a.astype(np.float64)-r.astype(np.float64)); dd=np.where(np.isnan(a)&np.isnan(r),0,dd)
     m=float(np.nanmax(dd)); worst=max(worst,m); nne+=int((dd!=0).sum())
+    if 0 < m <= 1e-4: print('WITHIN-TOLERANCE seed',seed,'max',m,'floats',int((dd!=0).sum()),'at',[tuple(int(v) for v in ix) for ix in np.argwhere(dd!=0)[:4]],flush=True)
     if m>1e-4 or not np.array_equal(np.isnan(a),np.isnan(r)) or (pr,sh)!=(st['primary'],st['shadow']):
         bad+=1; print('MISMATCH seed',seed,m,(pr,sh),(st['primary'],st['shadow']))
     if seed%250==0: print('progress',seed,worst,nne,flush=True)

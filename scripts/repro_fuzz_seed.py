@@ -12,7 +12,7 @@ d='/tmp/fzr'; os.makedirs(d, exist_ok=True); shutil.copy(ROOT+'/tests/golden/sce
 txt = many_lights_scene_sdl(seed) if seed % 5 == 0 else random_scene_sdl(seed, max_depth=4 if seed%2 else 3)
 open(d+"/f.sdl","w").write(txt)
 if len(sys.argv)>2: print(txt)
-s=c2.parseSceneFromFile(d+'/f.sdl'); s.setFrameSize(64,48); cam=s.beginFrame()
+s=c2.parseSceneFromFile(d+'/f.sdl'); W,H=(int(os.environ.get("FUZZ_W","64")),int(os.environ.get("FUZZ_H","48"))); s.setFrameSize(W,H); cam=s.beginFrame()
 ctx=c2.Context(0); ctx.uploadScene(s.desc)
 r=orc.render_frame(s.desc,cam,s.renderOpts(),8,{})
 for cr in (0,1):
