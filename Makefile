@@ -26,7 +26,11 @@ UNITS      := 0 1 2 3 4 5
 KOBJS      := $(foreach u,$(UNITS),$(BUILD)/c2rt_kernels_u$(u).o)
 HOBJS      := $(BUILD)/c2rt_api.o $(BUILD)/dsc.o $(BUILD)/scene.o $(BUILD)/host_api.o
 
-all: $(LIBNAME) oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so tests/fp64_lean_check
+# diagnostics build of the same library: c2rt_api.cpp with the environment hooks compiled in (-DC2RT_DIAG=1), linked
+# over the SAME kernel objects; tests and scripts that need a hook load it with C2RT_LIB_VARIANT=diag
+DIAGNAME   := chess2rt_amd/libc2rt_diag.so
+
+all: $(LIBNAME) $(if $(VARIANT),,$(DIAGNAME)) oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so tests/fp64_lean_check
 
 $(BUILD):
 	mkdir -p $(BUILD)
@@ -41,6 +45,12 @@ $(BUILD)/%.o: $(CSRC)/host/%.cpp $(CSRC)/host/scene.hpp $(CSRC)/host/dsc.hpp inc
 	g++ $(CXXFLAGS) -c $< -o $@
 
 $(LIBNAME): $(KOBJS) $(HOBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
+
+$(BUILD)/c2rt_api_diag.o: $(CSRC)/c2rt_api.cpp $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
+	g++ $(CXXFLAGS) $(EXTRA_HIPFLAGS) -DC2RT_DIAG=1 -c $< -o $@
+
+$(DIAGNAME): $(KOBJS) $(BUILD)/c2rt_api_diag.o $(filter-out $(BUILD)/c2rt_api.o,$(HOBJS))
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
 
 # device check of fp64_lean.h against the compiler's own divide / sqrt expansions (tests/test_gpu_parity.py runs it)

@@ -204,6 +204,11 @@ C2RT_HOST_SYMBOLS = {
     "c2rt_host_bmp_encode": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
     "c2rt_host_color_to_rgb32": (C.c_uint32, [_f32p]),
     "c2rt_host_free": (None, [_VP]),
+    "c2rt_host_transform_reset": (None, [_f64p]),
+    "c2rt_host_transform_scale": (None, [_f64p, C.c_double, C.c_double, C.c_double]),
+    "c2rt_host_transform_rotate": (None, [_f64p, C.c_double, C.c_double, C.c_double]),
+    "c2rt_host_transform_translate": (None, [_f64p, _f64p]),
+    "c2rt_host_transform_point": (None, [_f64p, _f64p, _f64p]),
 }
 
 _lib = None

@@ -27,6 +27,20 @@ using namespace c2rt;
 
 constexpr int kMaxChunks = 16;     /* row chunks of a host-output frame */
 
+/* Environment hooks (A/B measurement and test knobs: C2RT_EXACT, C2RT_NO_IDN, C2RT_DEBUG_CULL, C2RT_CSG_FIRST_CAP,
+ * C2RT_HOST_*) exist in the DIAGNOSTICS build only — chess2rt_amd/libc2rt_diag.so, this file compiled with
+ * -DC2RT_DIAG=1 over the same kernel objects (Makefile).  The product library reads no environment variable: a
+ * drop-in renderer does not change kernels on a stray variable (tests/test_abi_exports.py checks that libc2rt.so
+ * does not even import getenv). */
+#ifndef C2RT_DIAG
+#define C2RT_DIAG 0
+#endif
+#if C2RT_DIAG
+static const char *diag_env(const char *name) { return std::getenv(name); }
+#else
+static constexpr const char *diag_env(const char *) { return nullptr; }
+#endif
+
 struct c2rt_ctx {
     int device = 0;
     /* c2rt_init_multi: the further device slots of this (lead) context, each a complete
@@ -76,10 +90,14 @@ struct c2rt_ctx {
     uint32_t *tile_stats = nullptr; /* diagnostics (c2rt_debug_set_tile_stats): caller-owned device buffer */
     size_t retry_words = 0;
     bool counters_valid = false;
-    hipStream_t counters_stream = nullptr;
-    /* the stream of the last frame enqueued without a host sync (c2rt_render_frame_device); has_inflight
-     * is cleared by the blocking entry points */
-    hipStream_t inflight_stream = nullptr;
+    /* Ordering of frames enqueued without a host sync (c2rt_render_frame_device): ev_inflight is recorded on the
+     * caller's stream behind everything the frame queued there; the next frame of this context — on whatever
+     * stream — waits for it ON THE DEVICE (hipStreamWaitEvent: the call itself does not block), the blocking entry
+     * points and the counter read-back wait for it on the host.  The library never keeps the caller's stream
+     * handle: the stream may be destroyed the moment the call returns (an event recorded on a destroyed stream
+     * completes with the stream's work).  has_inflight: ev_inflight has been recorded and not yet waited for by
+     * the host. */
+    hipEvent_t ev_inflight = nullptr;
     bool has_inflight = false;
 };
 
@@ -362,12 +380,12 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
         p.cam_dv[i] = cam->down_left[i] - cam->up_left[i];
     }
     /* lean:: divides sample coordinates by the camera's frame size through these (c2rt_trace.inc, screen_ray);
-     * a frame size that is not a sane denominator (the ABI accepts any positive double), or C2RT_EXACT=1 in
-     * the environment (A/B runs: the compiler's IEEE divide / sqrt everywhere, as in rounds 1-2), sends
+     * a frame size that is not a sane denominator (the ABI accepts any positive double) — or, in the diagnostics
+     * build, C2RT_EXACT=1 (A/B runs: the compiler's IEEE divide / sqrt everywhere, as in rounds 1-2) — sends
      * every tile down the exact:: path */
     p.cam_rw = 1.0 / cam->frame_width;
     p.cam_rh = 1.0 / cam->frame_height;
-    static const bool env_exact = [] { const char *e = std::getenv("C2RT_EXACT"); return e && e[0] == '1'; }();
+    static const bool env_exact = [] { const char *e = diag_env("C2RT_EXACT"); return e && e[0] == '1'; }();
     const auto sane = [](double v) { return v >= 0x1p-100 && v < 0x1p100; };
     p.force_exact = (env_exact || !sane(cam->frame_width) || !sane(cam->frame_height)) ? 1u : 0u;
     p.width = o->width;
@@ -385,7 +403,7 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
     p.tile_stats = ctx->tile_stats;
     p.row_group_start = 0;
     p.planes_only = ctx->planes_only;
-    static const bool no_idn = [] { const char *e = std::getenv("C2RT_NO_IDN"); return e && e[0] == '1'; }(); /* A/B: the general instances */
+    static const bool no_idn = [] { const char *e = diag_env("C2RT_NO_IDN"); return e && e[0] == '1'; }(); /* diagnostics build, A/B: the general instances */
     p.all_identity = no_idn ? 0u : ctx->all_identity;
     p.ground_node = ctx->ground_node;
     p.ground_y = ctx->ground_y;
@@ -418,11 +436,11 @@ void fill_params(const c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_r
             for (uint32_t l = 0; l < p.n_cull_lights; ++l) light_side_of(cam, &ctx->light_pos[3 * (size_t)l], p.light_side[l]);
         }
     }
-    /* diagnostics hook (like C2RT_CSG_FIRST_CAP; frames are unchanged by construction, slower): C2RT_DEBUG_CULL bit 0:
+    /* diagnostics build only (like C2RT_CSG_FIRST_CAP; frames are unchanged by construction, slower): C2RT_DEBUG_CULL bit 0:
      * no culling rectangles at all; bit 1: no ground-plane refinement of the shadow mask; bit 2: no view-pyramid
      * culling of shadow rays */
     static const int debug_cull = [] {
-        const char *e = std::getenv("C2RT_DEBUG_CULL");
+        const char *e = diag_env("C2RT_DEBUG_CULL");
         const int v = e ? std::atoi(e) : 0;
         if (v) std::fprintf(stderr, "libc2rt: diagnostics hook C2RT_DEBUG_CULL=%d is active (culling partly disabled; frames are unchanged, slower)\n", v);
         return v;
@@ -565,10 +583,10 @@ int prepare_tile_masks(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, h
 int launch_frame(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStream_t stream)
 {
     const int levels = ctx->csg_levels;
-    /* test hook: C2RT_CSG_FIRST_CAP=<entries> shrinks the first pass's stack so that the overflow ->
-     * retry path runs on ordinary scenes (tests/test_gpu_parity.py); never below 1, never above full */
+    /* test hook (diagnostics build only): C2RT_CSG_FIRST_CAP=<entries> shrinks the first pass's stack so that the
+     * overflow -> retry path runs on ordinary scenes (tests/test_gpu_parity.py); never below 1, never above full */
     static const int forced_cap = [] {
-        const char *e = std::getenv("C2RT_CSG_FIRST_CAP");
+        const char *e = diag_env("C2RT_CSG_FIRST_CAP");
         const int v = e ? std::atoi(e) : 0;
         if (v > 0) std::fprintf(stderr, "libc2rt: test hook C2RT_CSG_FIRST_CAP=%d is active (first-pass CSG hit stacks shrunk; frames are unchanged, nested-CSG scenes are slower)\n", v);
         return v;
@@ -619,10 +637,7 @@ int render_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render
     if (p.local_rows == 0) return C2RT_OK;
     const int e = launch_frame(ctx, p, variant_of(ctx, cam), stream);
     if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
-    if (opts->count_rays) {
-        ctx->counters_valid = true;
-        ctx->counters_stream = stream;
-    }
+    if (opts->count_rays) ctx->counters_valid = true;
     return C2RT_OK;
 }
 
@@ -669,6 +684,7 @@ int c2rt_init(int device, c2rt_ctx **out)
     for (int i = 0; i < kMaxChunks; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chunk_done[i], hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_inflight, hipEventDisableTiming));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counters), 4 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemset(ctx->counters, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->probe), sizeof(c2rt_trace_result)));
@@ -741,6 +757,7 @@ void c2rt_destroy(c2rt_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+    if (ctx->ev_inflight) { (void)hipEventSynchronize(ctx->ev_inflight); (void)hipEventDestroy(ctx->ev_inflight); }
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->copy_stream2) { (void)hipStreamSynchronize(ctx->copy_stream2); (void)hipStreamDestroy(ctx->copy_stream2); }
@@ -1111,10 +1128,11 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
  * chunk i streams back over PCIe (copy stream) while chunk i+1 renders (and is encoded), and the
  * stop flag is polled between chunks (finer than the reference's between-pass polling).  Into
  * pageable memory: one launch, one copy — chunked copies into pageable memory are slower than one
- * (measured).  ctx->frame holds the float rows, followed by the packed rows for the RGB32 form. */
+ * (measured).  ctx->frame (ensure_staging) holds the float rows OR the display words, whichever is asked for;
+ * a frame the kernel stores straight into the page-locked destination has no staging buffer at all. */
 /* Host-output pipeline parameters (defaults measured on MI355X, profiles/r03_variants.md); the environment
- * variables exist for that measurement: C2RT_HOST_CHUNK_MB, C2RT_HOST_FIRST_FRAC, C2RT_HOST_COPY_STREAMS,
- * C2RT_HOST_DIRECT_STORE. */
+ * variables exist for that measurement, in the diagnostics build only: C2RT_HOST_CHUNK_MB, C2RT_HOST_FIRST_FRAC,
+ * C2RT_HOST_COPY_STREAMS, C2RT_HOST_DIRECT_STORE. */
 struct HostKnobs {
     size_t chunk_bytes = 13u << 20; /* 4K float frame (99.5 MB), ms by chunk count: 10 chunks 2.12, 9 2.04, 8 (this) 1.96, 7 1.98, 6 1.98, 5 2.02, 4 2.19 (copy alone: 1.75) */
     double first_frac = 1.0;        /* a smaller first chunk: no gain (the pipeline is copy-bound from the first copy on) */
@@ -1127,21 +1145,35 @@ static const HostKnobs &host_knobs()
 {
     static const HostKnobs k = [] {
         HostKnobs v;
-        if (const char *e = std::getenv("C2RT_HOST_CHUNK_MB")) { const double mb = std::atof(e); if (mb >= 0.25 && mb <= 1024) v.chunk_bytes = (size_t)(mb * (1u << 20)); }
-        if (const char *e = std::getenv("C2RT_HOST_FIRST_FRAC")) { const double f = std::atof(e); if (f > 0 && f <= 1) v.first_frac = f; }
-        if (const char *e = std::getenv("C2RT_HOST_COPY_STREAMS")) v.copy_streams = std::atoi(e) > 1 ? 2 : 1;
-        if (const char *e = std::getenv("C2RT_HOST_DIRECT_STORE")) v.direct_store = std::atoi(e);
+        if (const char *e = diag_env("C2RT_HOST_CHUNK_MB")) { const double mb = std::atof(e); if (mb >= 0.25 && mb <= 1024) v.chunk_bytes = (size_t)(mb * (1u << 20)); }
+        if (const char *e = diag_env("C2RT_HOST_FIRST_FRAC")) { const double f = std::atof(e); if (f > 0 && f <= 1) v.first_frac = f; }
+        if (const char *e = diag_env("C2RT_HOST_COPY_STREAMS")) v.copy_streams = std::atoi(e) > 1 ? 2 : 1;
+        if (const char *e = diag_env("C2RT_HOST_DIRECT_STORE")) v.direct_store = std::atoi(e);
         return v;
     }();
     return k;
+}
+
+static int ensure_staging(c2rt_ctx *c, size_t bytes)
+{
+    const size_t floats = (bytes + sizeof(float) - 1) / sizeof(float);
+    if (floats > c->frame_floats) {
+        if (c->frame) { (void)hipFree(c->frame); c->frame = nullptr; c->frame_floats = 0; }
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->frame), floats * sizeof(float)));
+        c->frame_floats = floats;
+    }
+    return C2RT_OK;
 }
 
 /* the blocking entry points: nothing of an earlier stream-async frame of this context may still be in flight
  * (it would share the retry list and the counters), and nothing is in flight when they return */
 static int drain_inflight(c2rt_ctx *ctx)
 {
-    if (ctx->has_inflight) HIP_TRY(ctx, hipStreamSynchronize(ctx->inflight_stream));
+    if (!ctx->has_inflight) return C2RT_OK;
+    /* cleared whatever the wait returns: an error of the earlier frame is reported ONCE, here, and the context
+     * stays usable (round-3 advisor: a failed sync used to leave has_inflight set for good) */
     ctx->has_inflight = false;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_inflight));
     return C2RT_OK;
 }
 
@@ -1161,12 +1193,8 @@ static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2r
     /* the display frame leaves the render kernel encoded (RenderParams::out_rgb32): 4 B per pixel in the
      * staging buffer, no float frame, no second kernel */
     const size_t px_bytes = out_rgb ? 3 * sizeof(float) : sizeof(uint32_t);
-    char *staging = reinterpret_cast<char *>(ctx->frame);
-    if (out_rgb) {
-        p.out = ctx->frame;
-    } else {
+    if (!out_rgb) {
         p.out = nullptr;
-        p.out_rgb32 = reinterpret_cast<uint32_t *>(ctx->frame);
         p.srgb_lut = ctx->srgb_lut;
     }
     char *dst = out_rgb ? reinterpret_cast<char *>(out_rgb) : reinterpret_cast<char *>(out_rgb32);
@@ -1178,7 +1206,8 @@ static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2r
     const KernelVariant variant = variant_of(ctx, cam);
     const HostKnobs &knobs = host_knobs();
     if (is_pinned && knobs.direct_store >= (out_rgb ? 2 : 1)) {
-        /* the kernel stores straight into the page-locked host frame over PCIe while it renders */
+        /* the kernel stores straight into the page-locked host frame over PCIe while it renders: one launch,
+         * no staging buffer; the stop flag is polled once, before the launch (include/c2rt.h) */
         void *mapped = nullptr;
         if (hipHostGetDevicePointer(&mapped, dst, 0) == hipSuccess && mapped) {
             if (out_rgb) p.out = static_cast<float *>(mapped); else p.out_rgb32 = static_cast<uint32_t *>(mapped);
@@ -1186,11 +1215,15 @@ static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2r
             const int e = launch_frame(ctx, p, variant, ctx->stream);
             if (e != 0) return fail(ctx, C2RT_ERR_HIP, "render kernel launch: %s", hipGetErrorString((hipError_t)e));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (opts->count_rays) { ctx->counters_valid = true; ctx->counters_stream = ctx->stream; }
+            if (opts->count_rays) ctx->counters_valid = true;
             return C2RT_OK;
         }
         (void)hipGetLastError();
     }
+    /* staging frame on the device: 12 B per pixel of float rows, or 4 B per pixel of display words */
+    if (const int st = ensure_staging(ctx, (size_t)rows * row_px * px_bytes)) return st;
+    char *staging = reinterpret_cast<char *>(ctx->frame);
+    if (out_rgb) p.out = ctx->frame; else p.out_rgb32 = reinterpret_cast<uint32_t *>(ctx->frame);
     /* Into a page-locked frame: row chunks, chunk i crossing PCIe on a copy stream while chunk i+1 renders.
      * The copy (99.5 MB of float frame at ~57 GB/s = 1.75 ms at 4K) is longer than the render (1.15 ms), so
      * the frame time is the first chunk's render + the copies back to back + whatever keeps them from being
@@ -1236,22 +1269,10 @@ static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2r
     HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream2));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (cancelled) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested during the frame");
-    if (opts->count_rays) {
-        ctx->counters_valid = true;
-        ctx->counters_stream = ctx->stream;
-    }
+    if (opts->count_rays) ctx->counters_valid = true;
     return C2RT_OK;
 }
 
-static int ensure_staging(c2rt_ctx *c, size_t floats)
-{
-    if (floats > c->frame_floats) {
-        if (c->frame) { (void)hipFree(c->frame); c->frame = nullptr; c->frame_floats = 0; }
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->frame), floats * sizeof(float)));
-        c->frame_floats = floats;
-    }
-    return C2RT_OK;
-}
 
 /* Interleaved strips of a multi-device context: kTileH rows (one tile row) — the finest deal the
  * kernel's tiling allows, which balances the sky / floor / object mix best. */
@@ -1290,7 +1311,7 @@ static int render_to_host_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, con
         if (rows == 0) continue;
         if (hipSetDevice(c->device) != hipSuccess) { st = fail(ctx, C2RT_ERR_HIP, "hipSetDevice(%d)", c->device); break; }
         const size_t px = (size_t)rows * W;
-        if ((st = ensure_staging(c, px * 3 + (out_rgb32 ? px : 0))) != C2RT_OK) { st = fail(ctx, st, "slot %u: %s", d, c->err.c_str()); break; }
+        if ((st = ensure_staging(c, px * px_bytes)) != C2RT_OK) { st = fail(ctx, st, "slot %u: %s", d, c->err.c_str()); break; }
         if (out_rgb) {
             p.out = c->frame;
         } else { /* display words straight out of the render kernel (RenderParams::out_rgb32) */
@@ -1327,10 +1348,7 @@ static int render_to_host_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, con
     (void)hipSetDevice(ctx->device);
     if (st != C2RT_OK) return st;
     if (cancelled) return fail(ctx, C2RT_ERR_CANCELLED, "stop requested during the frame");
-    if (opts->count_rays) {
-        ctx->counters_valid = true;
-        ctx->counters_stream = ctx->stream;
-    }
+    if (opts->count_rays) ctx->counters_valid = true;
     return C2RT_OK;
 }
 
@@ -1390,10 +1408,7 @@ static int render_device_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, cons
         if (e != hipSuccess && st == C2RT_OK) st = fail(ctx, C2RT_ERR_HIP, "hipStreamWaitEvent (slot %u): %s", d, hipGetErrorString(e));
     }
     if (st != C2RT_OK) return st;
-    if (opts->count_rays) {
-        ctx->counters_valid = true;
-        ctx->counters_stream = stream;
-    }
+    if (opts->count_rays) ctx->counters_valid = true;
     return C2RT_OK;
 }
 
@@ -1419,14 +1434,19 @@ int c2rt_render_frame_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const 
     if (!out_rgb_dev) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
     if ((st = check_multi_opts(ctx, opts)) != C2RT_OK) return st;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    /* one frame of a context in flight at a time across streams (include/c2rt.h): the retry list and the
-     * counters are per context, and two frames on two streams would race on them */
+    /* Frames of one context are ordered across streams (include/c2rt.h): the retry list, the mask table and the
+     * counters are per context, and two frames on two streams would race on them.  The order is made ON THE
+     * DEVICE — this stream waits for the event the previous frame left behind (a no-op within one stream) — so
+     * the call returns without waiting for that frame. */
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if (ctx->has_inflight && ctx->inflight_stream != stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->inflight_stream));
-    ctx->inflight_stream = stream;
-    ctx->has_inflight = true;
-    if (!ctx->peers.empty()) return render_device_multi(ctx, cam, opts, out_rgb_dev, stream);
-    return render_device(ctx, cam, opts, out_rgb_dev, stream);
+    if (ctx->has_inflight) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_inflight, 0));
+    st = !ctx->peers.empty() ? render_device_multi(ctx, cam, opts, out_rgb_dev, stream)
+                             : render_device(ctx, cam, opts, out_rgb_dev, stream);
+    /* also after a failed launch: whatever did get queued is ordered before the next frame */
+    const hipError_t rec = hipEventRecord(ctx->ev_inflight, stream);
+    if (rec == hipSuccess) ctx->has_inflight = true;
+    else if (st == C2RT_OK) st = fail(ctx, C2RT_ERR_HIP, "hipEventRecord(ev_inflight): %s", hipGetErrorString(rec));
+    return st;
 }
 
 int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_rgb,
@@ -1440,7 +1460,6 @@ int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
     if ((st = check_multi_opts(ctx, opts)) != C2RT_OK) return st;
     if (!ctx->peers.empty()) return render_to_host_multi(ctx, cam, opts, out_rgb, nullptr, stop_flag);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if ((st = ensure_staging(ctx, (size_t)c2rt_local_rows(opts) * opts->width * 3)) != C2RT_OK) return st;
     return render_to_host(ctx, cam, opts, out_rgb, nullptr, stop_flag);
 }
 
@@ -1501,7 +1520,7 @@ int c2rt_get_ray_stats(c2rt_ctx *ctx, c2rt_ray_stats *out)
     if (!ctx || !out) return C2RT_ERR_INVALID_ARG;
     if (!ctx->counters_valid) return fail(ctx, C2RT_ERR_INVALID_ARG, "last render did not count rays");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->counters_stream));
+    if (const int st = drain_inflight(ctx)) return st; /* a counted device-output frame may still be running */
     unsigned long long h[2];
     HIP_TRY(ctx, hipMemcpy(h, ctx->counters, sizeof h, hipMemcpyDeviceToHost));
     out->primary_rays = h[0];
@@ -1522,7 +1541,7 @@ int c2rt_get_csg_truncations(c2rt_ctx *ctx, uint64_t *out)
     if (!ctx || !out) return C2RT_ERR_INVALID_ARG;
     if (!ctx->counters_valid) return fail(ctx, C2RT_ERR_INVALID_ARG, "last render did not count rays");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->counters_stream));
+    if (const int st = drain_inflight(ctx)) return st;
     unsigned long long h = 0;
     HIP_TRY(ctx, hipMemcpy(&h, ctx->counters + 2, sizeof h, hipMemcpyDeviceToHost));
     *out = h;
@@ -1620,9 +1639,6 @@ int c2rt_render_frame_rgb32(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c
     if ((st = check_multi_opts(ctx, opts)) != C2RT_OK) return st;
     if (!ctx->peers.empty()) return render_to_host_multi(ctx, cam, opts, nullptr, out_rgb32, stop_flag);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t pixels = (size_t)c2rt_local_rows(opts) * opts->width;
-    /* staging: float frame followed by the packed frame */
-    if ((st = ensure_staging(ctx, pixels * 3 + pixels)) != C2RT_OK) return st;
     return render_to_host(ctx, cam, opts, nullptr, out_rgb32, stop_flag);
 }
 

@@ -283,4 +283,54 @@ uint32_t c2rt_host_color_to_rgb32(const float rgb[3]) { return colorToRGB32(rgb)
 
 void c2rt_host_free(void *p) { std::free(p); }
 
+// Transform (rt/transform.d:24-63) on the flat 30-double layout of c2rt_scene_desc::node_transform
+namespace {
+Transform transform_load(const double t[30])
+{
+    Transform x;
+    std::memcpy(&x.transform, t, 9 * sizeof(double));
+    std::memcpy(&x.inverseTransform, t + 9, 9 * sizeof(double));
+    std::memcpy(&x.transposedInverse, t + 18, 9 * sizeof(double));
+    x.offset = Vector(t[27], t[28], t[29]);
+    return x;
+}
+void transform_store(double t[30], const Transform &x)
+{
+    std::memcpy(t, &x.transform, 9 * sizeof(double));
+    std::memcpy(t + 9, &x.inverseTransform, 9 * sizeof(double));
+    std::memcpy(t + 18, &x.transposedInverse, 9 * sizeof(double));
+    t[27] = x.offset.x, t[28] = x.offset.y, t[29] = x.offset.z;
+}
+} // namespace
+void c2rt_host_transform_reset(double t[30])
+{
+    Transform x;
+    x.reset();
+    transform_store(t, x);
+}
+void c2rt_host_transform_scale(double t[30], double x, double y, double z)
+{
+    Transform tr = transform_load(t);
+    tr.scale(x, y, z);
+    transform_store(t, tr);
+}
+void c2rt_host_transform_rotate(double t[30], double yaw, double pitch, double roll)
+{
+    Transform tr = transform_load(t);
+    tr.rotate(yaw, pitch, roll);
+    transform_store(t, tr);
+}
+void c2rt_host_transform_translate(double t[30], const double v[3])
+{
+    Transform tr = transform_load(t);
+    tr.translate(Vector(v[0], v[1], v[2]));
+    transform_store(t, tr);
+}
+void c2rt_host_transform_point(const double t[30], const double p[3], double out[3])
+{
+    const Transform tr = transform_load(t);
+    const Vector r = mul(Vector(p[0], p[1], p[2]), tr.transform); // rt/transform.d:57-63
+    out[0] = r.x + tr.offset.x, out[1] = r.y + tr.offset.y, out[2] = r.z + tr.offset.z;
+}
+
 } // extern "C"

@@ -22,16 +22,13 @@
  *   - one context per process and GPU; calls on a context are serialised by
  *     the caller (the reference has a single render thread).
  *
- * Environment (read once per process; measurement and test knobs, none of them
- * changes a pixel): C2RT_EXACT=1 — every tile through the compiler's IEEE divide
- * / sqrt (the round-2 arithmetic) instead of the shortened sequences;
- * C2RT_NO_IDN=1 — the general kernel instances also for scenes whose node
- * matrices are all the identity; C2RT_HOST_CHUNK_MB / C2RT_HOST_FIRST_FRAC /
- * C2RT_HOST_COPY_STREAMS / C2RT_HOST_DIRECT_STORE — the host-output pipeline of
- * c2rt_render_frame; C2RT_CSG_FIRST_CAP=<n> — test hook: first-pass CSG hit
- * stacks of n entries; C2RT_DEBUG_CULL=<bits> — diagnostics hook: 1 no culling
- * rectangles, 2 no ground-plane refinement of the shadow mask, 4 no
- * view-pyramid culling of shadow rays (both announced on stderr when set).
+ * Environment: the product library (libc2rt.so) reads NO environment variable.
+ * The measurement / test knobs of earlier rounds (C2RT_EXACT, C2RT_NO_IDN,
+ * C2RT_HOST_CHUNK_MB / _FIRST_FRAC / _COPY_STREAMS / _DIRECT_STORE,
+ * C2RT_CSG_FIRST_CAP, C2RT_DEBUG_CULL — none changes a pixel) exist only in the
+ * diagnostics build, chess2rt_amd/libc2rt_diag.so (`make`: c2rt_api.cpp with
+ * -DC2RT_DIAG=1 over the same kernel objects), where each is read once per
+ * process; chess2rt_amd/csrc/c2rt_api.cpp documents them at their sites.
  */
 #ifndef C2RT_H
 #define C2RT_H
@@ -281,8 +278,12 @@ uint32_t c2rt_local_rows(const c2rt_render_opts *opts);
 
 /* Blocking frame render into caller-owned HOST memory (`Image!Color.pixels`):
  * the drop-in for `Renderer.renderRT()` (rt/renderer.d:83-192).  Writes
- * local_rows*width*3 floats.  `stop_flag` (nullable) is polled between
- * passes like `isStopReq()` (rt/renderer.d:93-97,129,147,180). */
+ * local_rows*width*3 floats.  `stop_flag` (nullable) is polled like
+ * `isStopReq()` (rt/renderer.d:93-97,129,147,180): before the frame and, for a
+ * frame that goes back in row chunks (a page-locked float frame), between the
+ * chunks.  A frame made by ONE launch — pageable destination, or display words
+ * stored straight into a page-locked frame (c2rt_render_frame_rgb32) — polls it
+ * once, before the launch; C2RT_ERR_CANCELLED leaves the frame unspecified. */
 int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam,
                       const c2rt_render_opts *opts, float *out_rgb,
                       const volatile uint8_t *stop_flag);
@@ -299,17 +300,19 @@ int c2rt_unpin_host_buffer(c2rt_ctx *ctx, float *out_rgb);
  * (e.g. a torch tensor's data_ptr) and the kernels are enqueued on
  * `hip_stream` (a hipStream_t, NULL = default stream) without a host sync.
  * Frames of ONE context are ordered: per-frame scratch of the context (the
- * nested-CSG retry list, the ray counters) belongs to the frame in flight, so
- * a frame enqueued on a DIFFERENT stream than the context's previous frame
- * first waits, on the host, for that previous stream to drain
- * (hipStreamSynchronize) — correct, but no overlap: keep a context on one
- * stream, and use one context per stream for frames that should overlap. */
+ * nested-CSG retry list, the tile-mask table, the ray counters) belongs to the
+ * frame in flight, so a frame enqueued on a DIFFERENT stream than the
+ * context's previous frame is ordered behind it ON THE DEVICE (an event the
+ * previous frame left on its stream + hipStreamWaitEvent): the call returns at
+ * once, but the two frames do not overlap — use one context per stream for
+ * frames that should.  The library keeps no reference to `hip_stream`: the
+ * caller may destroy it as soon as the call has returned. */
 int c2rt_render_frame_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam,
                              const c2rt_render_opts *opts, float *out_rgb_dev,
                              void *hip_stream);
 
 /* Ray counters of the last render call made with opts->count_rays = 1
- * (synchronises the stream of that call). */
+ * (waits, on the host, for that frame to complete). */
 int c2rt_get_ray_stats(c2rt_ctx *ctx, c2rt_ray_stats *out);
 
 /* CsgOp child hit lists that reached C2RT_MAX_CSG_HITS during the last render call made with

@@ -14,6 +14,7 @@
  *   renderSceneAsync     rt/renderer.d:23-44
  *   renderPixel          rt/renderer.d:46-57
  *   Camera.move/rotate   rt/camera.d:181-229
+ *   Transform            rt/transform.d:24-63
  *   Bitmap.loadImage     rt/bitmap.d:67-80, imageio/bmp.d:60-193
  *   Bitmap.saveImage     rt/bitmap.d:84-103, imageio/bmp.d:195-237
  */
@@ -107,6 +108,17 @@ int c2rt_host_bmp_encode(const float *rgb, uint32_t width, uint32_t height, uint
                          size_t *out_len);
 uint32_t c2rt_host_color_to_rgb32(const float rgb[3]);
 void c2rt_host_free(void *p);
+
+/* Transform (rt/transform.d:24-63) as the loader's mirror evaluates it.  `t` holds transform[9],
+ * inverseTransform[9], transposedInverse[9] (row-major) and offset[3] — the layout of
+ * c2rt_scene_desc::node_transform.  The REAL rotate (Rx(pitch) * Ry(yaw) * Rz(roll), :41-50) is reachable only
+ * here: the scene loader's "rotate" key scales (reference bug). */
+void c2rt_host_transform_reset(double t[30]);
+void c2rt_host_transform_scale(double t[30], double x, double y, double z);
+void c2rt_host_transform_rotate(double t[30], double yaw, double pitch, double roll);
+void c2rt_host_transform_translate(double t[30], const double v[3]);
+/* point(P) = mul(P, transform) + offset (:57-63) */
+void c2rt_host_transform_point(const double t[30], const double p[3], double out[3]);
 
 #ifdef __cplusplus
 }

@@ -18,16 +18,9 @@ import chess2rt_amd as c2
 import oracle_lib as orc
 from chess2rt_amd import _abi
 from golden_configs import CONFIGS, SCENES, crop_offsets, load_config
+from parity_util import TOL, maxdiff  # TOL = 1e-4 per RGB channel, BASELINE.json; one-sided NaN / inf fail
 
 pytestmark = pytest.mark.gpu
-
-TOL = 1e-4  # per RGB channel, BASELINE.json
-
-
-def maxdiff(a, b):
-    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
-    d = np.where(np.isnan(a) & np.isnan(b), 0.0, d)
-    return float(np.nanmax(d)) if d.size else 0.0, int((d > TOL).sum()), int((d != 0).sum())
 
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
@@ -696,6 +689,56 @@ def test_rgb32_frame_and_strips(gpu_ctx):
     finally:
         gpu_ctx.unpinHostBuffer(pinned)
     assert np.array_equal(pinned, whole)
+    # the PRODUCTION (uncounted, lean::) instance storing display words straight into the page-locked frame over
+    # PCIe (render_to_host's direct-store branch: no staging buffer), whole frame and strips
+    o3 = scene.renderOpts(taps=1)
+    pinned = np.zeros((1001, 1283), np.uint32)
+    gpu_ctx.pinHostBuffer(pinned)
+    try:
+        gpu_ctx.renderFrameRGB32Into(cam2, o3, pinned)
+        assert np.array_equal(pinned, whole)
+        o4 = scene.renderOpts(taps=1, strip_height=8, strip_rank=2, strip_world=5)
+        rows = [y for y in range(1001) if (y // 8) % 5 == 2]
+        pinned[:] = 0
+        gpu_ctx.renderFrameRGB32Into(cam2, o4, pinned[: len(rows)])
+        assert np.array_equal(pinned[: len(rows)], whole[rows]) and not pinned[len(rows):].any()
+    finally:
+        gpu_ctx.unpinHostBuffer(pinned)
+
+
+def test_float_frame_stored_straight_into_the_pinned_buffer():
+    """C2RT_HOST_DIRECT_STORE=2 (diagnostics build): the float frame too is stored by the kernel straight into the
+    page-locked destination (12-byte stores over PCIe; slower than the chunked copy, which is why it is not the
+    default) — production and counting instances, frames equal the staged ones bit for bit."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import chess2rt_amd as c2
+from golden_configs import load_config
+assert c2._abi.LIB_PATH.endswith("libc2rt_diag.so")
+ctx = c2.Context(0)
+scene, cam, opts = load_config("lecture5_333x217_t4")
+ctx.uploadScene(scene.desc)
+staged = ctx.renderFrame(cam, opts)                      # pageable destination: staging buffer + one copy
+for count in (0, 1):
+    _, _, o = load_config("lecture5_333x217_t4", count_rays=count)
+    pinned = np.full(staged.shape, -1.0, np.float32)
+    ctx.pinHostBuffer(pinned)
+    try:
+        ctx.renderFrameInto(cam, o, pinned)
+    finally:
+        ctx.unpinHostBuffer(pinned)
+    assert np.array_equal(pinned.view(np.uint32), staged.view(np.uint32)), count
+print("ok")
+'''
+    env = dict(os.environ, C2RT_HOST_DIRECT_STORE="2", C2RT_LIB_VARIANT="diag")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout + p.stderr
 
 
 def test_plain_c_caller_matches_oracle(tmp_path):
@@ -795,8 +838,9 @@ def test_two_scenes_alternating_on_one_context(gpu_ctx):
 @pytest.mark.parametrize("cap", [1, 3, 6, 11])
 def test_csg_hit_stack_overflow_is_redone_at_full_capacity(cap):
     """Nested-CSG scenes run with a reduced LDS hit stack first; tiles in which a lane's nested lists
-    outgrow it are rendered again by the full-capacity launch.  C2RT_CSG_FIRST_CAP (a test hook read
-    at library load) forces tiny stacks, so that most CSG tiles of ordinary scenes take that path: the
+    outgrow it are rendered again by the full-capacity launch.  C2RT_CSG_FIRST_CAP (a test hook of the
+    DIAGNOSTICS build, chess2rt_amd/libc2rt_diag.so: the same kernel objects under a c2rt_api.cpp compiled with
+    the environment hooks) forces tiny stacks, so that most CSG tiles of ordinary scenes take that path: the
     frames, the ray counts and a strip-sharded render must not change."""
     import subprocess
     import sys
@@ -823,7 +867,7 @@ for name in ("csg_stress_320x240_t5", "csg_corner_256x192_t1"):
     assert np.array_equal(b.view(np.uint32), ref[rows].view(np.uint32)), name
 print("ok")
 '''
-    env = dict(os.environ, C2RT_CSG_FIRST_CAP=str(cap))
+    env = dict(os.environ, C2RT_CSG_FIRST_CAP=str(cap), C2RT_LIB_VARIANT="diag")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert p.returncode == 0 and "ok" in p.stdout, p.stdout + p.stderr
@@ -911,6 +955,93 @@ def test_baseline_configs_4_and_5_full_frames(gpu_ctx, scene_file, w, h, taps, r
     assert got == (st["primary"], st["shadow"])
     if rays:
         assert got[0] == rays
+
+
+def test_zaphod_as_shipped_full_size_dof25(gpu_ctx):
+    """zaphod.sdl exactly as the file ships — depth of field on, 25 lens samples per pixel (rt/camera.d:154-173,
+    rt/renderer.d:270-287; the lens draws from the build's counter RNG on both sides) — at
+    3840x2160, the frame bench.py times as `zaphod_4k_dof25`: every float against the oracle on all host cores."""
+    s = c2.parseSceneFromFile(os.path.join(SCENES, "zaphod.sdl"))
+    s.setFrameSize(3840, 2160)
+    cam = s.beginFrame()
+    assert cam.dof == 1 and cam.num_samples == 25
+    opts = s.renderOpts(taps=c2.TAPS_1, count_rays=1, seed=7)
+    gpu_ctx.uploadScene(s.desc)
+    gpu = gpu_ctx.renderFrame(cam, opts)
+    got = gpu_ctx.rayStats()
+    st = {}
+    ref = orc.render_frame(s.desc, cam, opts, 0, st)
+    md, nbad, nne = maxdiff(gpu, ref)
+    print("zaphod.sdl 3840x2160 DOF x25: max|d|=%.3g, !=: %d of %d floats" % (md, nne, gpu.size))
+    assert md <= TOL and nbad == 0
+    assert got == (st["primary"], st["shadow"]) and got[0] == 3840 * 2160 * 25
+
+
+def test_zaphod_anchor_pixels_on_the_gpu(gpu_ctx, golden_dir):
+    """The independent yaw / roll anchors (tests/golden/zaphod_anchors.json, derived by
+    tests/golden/make_zaphod_anchors.py without the oracle or the host mirror) against the HIP path itself:
+    the probe's ray, hit and colour, and the frame kernel's pixel."""
+    a = json.load(open(os.path.join(golden_dir, "zaphod_anchors.json")))
+    s = c2.parseSceneFromFile(os.path.join(SCENES, a["scene"]))
+    s.setFrameSize(a["width"], a["height"])
+    s.setAA(False)
+    s.setDof(False)
+    cam = s.beginFrame()
+    opts = s.renderOpts()
+    gpu_ctx.uploadScene(s.desc)
+    frame = gpu_ctx.renderFrame(cam, opts)
+    for px in a["pixels"]:
+        g = gpu_ctx.renderPixel(cam, opts, px["x"], px["y"])
+        assert g.closest_node == 0
+        np.testing.assert_allclose(list(g.ray_dir), px["dir"], atol=a["dir_tolerance"], rtol=0)
+        np.testing.assert_allclose(list(g.p), px["p"], atol=a["geom_tolerance"], rtol=0)
+        np.testing.assert_allclose([g.dist, g.u, g.v], [px["t"], px["u"], px["v"]], atol=a["geom_tolerance"], rtol=0)
+        np.testing.assert_allclose(list(g.color), px["rgb"], atol=a["rgb_tolerance"], rtol=0)
+        np.testing.assert_allclose(frame[px["y"], px["x"]], px["rgb"], atol=a["rgb_tolerance"], rtol=0)
+
+
+LIBM_RESIDUAL = dict(seed=12023564, sizes=((64, 48), (128, 96), (200, 152), (320, 240)))
+
+
+def test_device_libm_residual_is_inside_the_tolerance(gpu_ctx, tmp_path, scenes_dir):
+    """The one KNOWN float (of 2.7e9 swept offline) that is not the oracle's: fuzz seed
+    12023564, a Phong lobe with exponent 2.04391 where the device's libm `pow` and glibc's round the double
+    differently — 1 ulp of one fp32 channel of one pixel.  This is why the claim is "<= 1e-4 with bit-identical
+    frames on everything else", not "bit-identical by construction"; the suite holds the case so the residual is
+    visible where the driver looks: the difference is there (> 0), far inside the tolerance (<= 1e-4, in fact
+    <= 1e-6), in a handful of floats at most, and the probe kernel returns what the frame kernel returns (it is
+    the device's arithmetic, not a frame-kernel shortcut)."""
+    import shutil
+
+    from scene_fuzz import random_scene_sdl
+
+    shutil.copy(os.path.join(scenes_dir, "floor.bmp"), tmp_path / "floor.bmp")
+    seed = LIBM_RESIDUAL["seed"]
+    path = tmp_path / "residual.sdl"
+    path.write_text(random_scene_sdl(seed, max_depth=4 if seed % 2 else 3))     # scripts/fuzz_big.py's generator call
+    s = c2.parseSceneFromFile(str(path))
+    seen = []
+    for (w, h) in LIBM_RESIDUAL["sizes"]:
+        s.setFrameSize(w, h)
+        cam = s.beginFrame()
+        opts = s.renderOpts(count_rays=1)
+        gpu_ctx.uploadScene(s.desc)
+        a = gpu_ctx.renderFrame(cam, opts)
+        got = gpu_ctx.rayStats()
+        st = {}
+        ref = orc.render_frame(s.desc, cam, opts, 0, st)
+        md, nbad, nne = maxdiff(a, ref)
+        assert md <= TOL and nbad == 0 and got == (st["primary"], st["shadow"]), (w, h, md)
+        assert md <= 1e-6 and nne <= 4, (w, h, md, nne)
+        for (y, x, ch) in np.argwhere(a.view(np.uint32) != ref.view(np.uint32)):
+            g = gpu_ctx.renderPixel(cam, s.renderOpts(), int(x), int(y))
+            o = orc.render_pixel(s.desc, cam, s.renderOpts(), int(x), int(y))
+            assert np.float32(g.color[ch]) == a[y, x, ch] != ref[y, x, ch] == np.float32(o.color[ch])
+            assert abs(int(a.view(np.uint32)[y, x, ch]) - int(ref.view(np.uint32)[y, x, ch])) == 1     # one ulp
+            assert (g.closest_node, g.leaf_geom, g.dist, list(g.p)) == (o.closest_node, o.leaf_geom, o.dist, list(o.p))
+            seen.append((w, h, int(x), int(y), int(ch), float(md)))
+    print("libm residual:", seen)
+    assert seen, "the device-libm residual of seed %d did not show at any swept frame size" % seed
 
 
 def test_planes_only_scenes(gpu_ctx, tmp_path, scenes_dir):
@@ -1122,8 +1253,9 @@ def test_interactive_camera_sequence_matches_the_oracle(gpu_ctx):
 
 def test_frames_of_one_context_on_two_streams_are_ordered(gpu_ctx):
     """c2rt_render_frame_device on two different streams of ONE context, back to back, for a nested-CSG scene
-    (its frames use the context's retry list): include/c2rt.h promises that the second frame first waits for the
-    first stream, so both frames are complete and equal the frames rendered alone."""
+    (its frames use the context's retry list): include/c2rt.h promises that the second frame is ordered behind
+    the first ON THE DEVICE (event + hipStreamWaitEvent), so both frames are complete and equal the frames
+    rendered alone — and the second call returns without waiting for the first frame."""
     import torch
 
     scene, cam_a, opts = load_config("csg_stress_320x240_t1")
@@ -1153,3 +1285,61 @@ def test_frames_of_one_context_on_two_streams_are_ordered(gpu_ctx):
     host = gpu_ctx.renderFrame(cam_a, opts)
     torch.cuda.synchronize(dev)
     assert np.array_equal(host, alone[0].cpu().numpy()) and torch.equal(b, alone[1])
+    # the ordering does not block the host: a long frame (2048x1536 x5 taps of the depth-4 scene, several ms) on
+    # s1, then a frame on s2 — the second CALL is back while the first FRAME is still running
+    big = scene.renderOpts(taps=c2.TAPS_REF5)
+    scene.setFrameSize(2048, 1536)
+    cam_big = scene.beginFrame()
+    big = scene.renderOpts(taps=c2.TAPS_REF5)
+    t_big = torch.empty((1536, 2048, 3), dtype=torch.float32, device=dev)
+    gpu_ctx.renderFrameDevice(cam_big, big, t_big.data_ptr(), s1.cuda_stream)      # warm-up (allocations)
+    torch.cuda.synchronize(dev)
+    done = torch.cuda.Event()
+    gpu_ctx.renderFrameDevice(cam_big, big, t_big.data_ptr(), s1.cuda_stream)
+    done.record(s1)
+    gpu_ctx.renderFrameDevice(cam_b, opts, b.data_ptr(), s2.cuda_stream)
+    first_still_running = not done.query()
+    torch.cuda.synchronize(dev)
+    assert first_still_running, "c2rt_render_frame_device waited on the host for the previous stream's frame"
+    assert torch.equal(b, alone[1])
+
+
+def test_the_callers_stream_may_be_destroyed_after_the_call(gpu_ctx):
+    """The library keeps no reference to the caller's stream (round-3 advisor): render on a stream, destroy it,
+    then every kind of call on the same context still works — blocking frames, the ray counters of the frame that
+    ran on the destroyed stream, a frame on another stream, pin / unpin."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    scene, cam, opts = load_config("csg_stress_320x240_t1", count_rays=1)
+    gpu_ctx.uploadScene(scene.desc)
+    want = gpu_ctx.renderFrame(cam, opts)
+    rays = gpu_ctx.rayStats()
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), want.nbytes) == 0
+    try:
+        for _ in range(3):
+            st = C.c_void_p()
+            assert hip.hipStreamCreate(C.byref(st)) == 0
+            gpu_ctx.renderFrameDevice(cam, opts, dev.value, st.value)
+            assert hip.hipStreamDestroy(st) == 0          # drains the stream's work, then the handle is gone
+            assert gpu_ctx.rayStats() == rays              # counters of the frame that ran on it
+            st2 = C.c_void_p()
+            assert hip.hipStreamCreate(C.byref(st2)) == 0
+            gpu_ctx.renderFrameDevice(cam, opts, dev.value, st2.value)     # orders itself behind the dead stream's event
+            host = gpu_ctx.renderFrame(cam, opts)                          # blocking entry point drains first
+            assert np.array_equal(host, want)
+            got = np.empty_like(want)
+            assert hip.hipMemcpy(got.ctypes.data, dev, want.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+            assert np.array_equal(got, want)
+            assert hip.hipStreamDestroy(st2) == 0
+            pinned = np.zeros_like(want)
+            gpu_ctx.pinHostBuffer(pinned)
+            gpu_ctx.renderFrameInto(cam, opts, pinned)
+            gpu_ctx.unpinHostBuffer(pinned)
+            assert np.array_equal(pinned, want)
+    finally:
+        hip.hipFree(dev)

@@ -64,6 +64,73 @@ def test_lecture4_anchors(golden_dir):
             assert abs(r.dist - px["t"]) < a["geom_tolerance"]
 
 
+def _transform_through(reset, scale, rotate, translate, ops):
+    t = (C.c_double * 30)()
+    reset(t)
+    for op in ops:
+        if op[0] == "scale":
+            scale(t, *map(float, op[1:]))
+        elif op[0] == "rotate":
+            rotate(t, *map(float, op[1:]))
+        else:
+            translate(t, (C.c_double * 3)(*map(float, op[1:])))
+    return t
+
+
+def test_zaphod_anchors_pin_yaw_roll_and_transform(golden_dir):
+    """Independent anchors (tests/golden/make_zaphod_anchors.py: closed forms in 50-digit arithmetic with the gfm
+    conventions written out and their signs tied to the reference's key bindings) for what lecture4 cannot
+    constrain: yaw and roll of Camera.beginFrame, and Transform.scale / rotate / translate / point.  The oracle
+    AND the host mirror are each compared with the anchors (a shared wrong convention would be common-mode
+    between them and invisible to every GPU-vs-oracle test)."""
+    a = jload(golden_dir, "zaphod_anchors.json")
+    scene = c2.parseSceneFromFile(os.path.join(SCENES, a["scene"]))
+    scene.setFrameSize(a["width"], a["height"])
+    scene.setAA(False)
+    scene.setDof(False)
+    cam = scene.beginFrame()                             # host mirror (chess2rt_amd/csrc/host/scene.cpp)
+    hc = scene.camera
+    ocam = _abi.CameraFrame()                            # the oracle's own Camera.beginFrame
+    orc.lib().orc_camera_begin_frame(orc.vec3(*hc.pos), hc.yaw, hc.pitch, hc.roll, hc.fov, a["width"], a["height"], C.byref(ocam))
+    assert (hc.yaw, hc.pitch, hc.roll) == (5.2, -41.8, 2.3)
+    for who, frame in (("host", cam), ("oracle", ocam)):
+        for k in ("up_left", "up_right", "down_left", "right_dir", "up_dir", "front_dir"):
+            np.testing.assert_allclose(list(getattr(frame, k)), a["camera"][k], atol=a["camera"]["tolerance"], rtol=0, err_msg=who + " " + k)
+    # a flipped yaw or roll sign moves these by far more than the tolerance: the anchors do constrain them
+    assert abs(a["camera"]["front_dir"][0]) > 0.05 and abs(a["camera"]["right_dir"][1]) > 0.02
+    opts = scene.renderOpts()
+    assert cam.dof == 0 and opts.taps == c2.TAPS_1
+    for px in a["pixels"]:
+        r = orc.render_pixel(scene.desc, cam, opts, px["x"], px["y"])
+        assert r.closest_node == 0
+        np.testing.assert_allclose(list(r.ray_dir), px["dir"], atol=a["dir_tolerance"], rtol=0)
+        np.testing.assert_allclose(list(r.p), px["p"], atol=a["geom_tolerance"], rtol=0)
+        np.testing.assert_allclose([r.dist, r.u, r.v], [px["t"], px["u"], px["v"]], atol=a["geom_tolerance"], rtol=0)
+        np.testing.assert_allclose(list(r.color), px["rgb"], atol=a["rgb_tolerance"], rtol=0)
+    # whole-frame oracle render agrees with its probe at the anchored pixels (frame path == probe path)
+    frame = orc.render_frame(scene.desc, cam, opts, 0)
+    for px in a["pixels"]:
+        np.testing.assert_allclose(frame[px["y"], px["x"]], px["rgb"], atol=a["rgb_tolerance"], rtol=0)
+    # Transform: the oracle's and the host mirror's, each against the closed forms
+    L, H = orc.lib(), _abi.load_library()
+    for case in a["transforms"]:
+        for who, fns in (("oracle", (L.orc_transform_reset, L.orc_transform_scale, L.orc_transform_rotate, L.orc_transform_translate)),
+                         ("host", (H.c2rt_host_transform_reset, H.c2rt_host_transform_scale, H.c2rt_host_transform_rotate, H.c2rt_host_transform_translate))):
+            t = _transform_through(*fns, case["ops"])
+            for key, lo in (("transform", 0), ("inverse", 9), ("transposed_inverse", 18)):
+                np.testing.assert_allclose(np.array(t[lo:lo + 9]).reshape(3, 3), np.array(case[key], float),
+                                           atol=a["matrix_tolerance"] * 10, rtol=0, err_msg="%s %s %s" % (who, key, case["note"]))
+            assert list(t[27:30]) == [float(x) for x in case["offset"]]
+            if "point_in" in case and who == "host":
+                out = (C.c_double * 3)()
+                H.c2rt_host_transform_point(t, (C.c_double * 3)(*case["point_in"]), out)
+                np.testing.assert_allclose(list(out), case["point_out"], atol=1e-14, rtol=0)
+    # and the loader's node table for zaphod.sdl is the first case, bit for bit
+    t = _transform_through(H.c2rt_host_transform_reset, H.c2rt_host_transform_scale, H.c2rt_host_transform_rotate,
+                           H.c2rt_host_transform_translate, a["transforms"][0]["ops"])
+    assert [scene.desc.contents.node_transform[i] for i in range(30)] == list(t)
+
+
 # ---- (3) properties of the reference algorithm --------------------------------
 def _mini_scene(geoms, children=None):
     """A SceneDesc with only geometries (for Geometry.intersect calls)."""
