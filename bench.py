@@ -415,30 +415,25 @@ def measure(torch, dist, pipe, steps, warmup, world, dev):
 
 
 def measure_pipelined(torch, c2, ctx, scene, cam, opts, steps, warmup, dev):
-    """N=1: TWO frames in flight — two contexts (frames of one context are ordered, include/c2rt.h), two streams,
-    two output buffers, frames enqueued alternately: a frame's launch gap and the under-filled tail of its grid
-    are covered by the other frame's waves.  Throughput of a frame SEQUENCE (an animation, the GUI's camera loop
-    rendered ahead); a single frame's latency is the serial figure.  Returns seconds for `steps` frames."""
-    ctx2 = c2.Context(dev.index or 0)
-    try:
-        ctx2.uploadScene(scene.desc)
-        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        ctxs = [ctx, ctx2]
-        outs = [torch.empty((opts.height, opts.width, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+    """N=1: TWO frames in flight — ONE context, two streams (frames of a context on different streams are
+    independent: each stream has its own per-frame scratch, include/c2rt.h), two output buffers, frames enqueued
+    alternately: a frame's launch gap and the under-filled tail of its grid are covered by the other frame's waves.
+    Throughput of a frame SEQUENCE (an animation, the GUI's camera loop rendered ahead); a single frame's latency is
+    the serial figure.  Returns seconds for `steps` frames."""
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = [torch.empty((opts.height, opts.width, 3), dtype=torch.float32, device=dev) for _ in range(2)]
 
-        def frame(i):
-            ctxs[i & 1].renderFrameDevice(cam, opts, outs[i & 1].data_ptr(), streams[i & 1].cuda_stream)
+    def frame(i):
+        ctx.renderFrameDevice(cam, opts, outs[i & 1].data_ptr(), streams[i & 1].cuda_stream)
 
-        for i in range(2 * max(1, warmup)):
-            frame(i)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            frame(i)
-        torch.cuda.synchronize(dev)
-        return time.perf_counter() - t0
-    finally:
-        ctx2.close()
+    for i in range(2 * max(1, warmup)):
+        frame(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        frame(i)
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
 
 
 def smi_sample():
@@ -911,7 +906,7 @@ def main():
                                                 "note": "an fma counts once; the rest of the VALU stream (roofline.valu) is compares, selects, moves, integer and fp32 work"}
         if r.get("pipelined"):
             out["config"]["two_frames_in_flight"] = {"Mray_per_s": rays_per_frame * r["steps"] / r["pipelined"] / 1e6, "ms_per_frame": r["pipelined"] / r["steps"] * 1e3,
-                                                     "note": "two contexts on two streams, frames enqueued alternately: launch gaps and grid tails filled by the other frame; never `value`"}
+                                                     "note": "one context, two streams, frames enqueued alternately: launch gaps and grid tails filled by the other frame; never `value`"}
         if world == 1 and not args.no_sustained:
             try:
                 out["sustained"] = sustained_leg(torch, pipe, dev)

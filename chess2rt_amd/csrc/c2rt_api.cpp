@@ -27,6 +27,23 @@ using namespace c2rt;
 
 constexpr int kMaxChunks = 16;     /* row chunks of a host-output frame */
 
+/* Per-frame scratch a launch writes before it reads it — the tile-mask table (pre-pass kernel) and the nested-CSG
+ * retry list — exists once per STREAM the context has rendered on (up to kScratchSlots of them), keyed by the
+ * stream handle (compared, never dereferenced).  Frames on one stream are in order and share a slot; frames on
+ * different streams touch different slots, so they need no ordering at all: no event per frame (an event record
+ * is a ~2 us gap in the queue: 6 % of a 1080p lecture4 frame) and frames of one context may overlap.  A 17th
+ * stream recycles the least recently used slot after a device sync (the one place a frame call can block). */
+constexpr int kScratchSlots = 16;
+struct FrameScratch {
+    const void *key = nullptr;
+    bool used = false;
+    uint64_t tick = 0;
+    uint32_t *tile_masks = nullptr; /* RenderParams::tile_masks: 4 words per tile of the frame's local rows */
+    size_t tile_mask_entries = 0;
+    uint32_t *retry_list = nullptr; /* RenderParams::retry_list: [0] count, then tile (block) indices */
+    size_t retry_words = 0;
+};
+
 /* Environment hooks (A/B measurement and test knobs: C2RT_EXACT, C2RT_NO_IDN, C2RT_DEBUG_CULL, C2RT_CSG_FIRST_CAP,
  * C2RT_HOST_*) exist in the DIAGNOSTICS build only — chess2rt_amd/libc2rt_diag.so, this file compiled with
  * -DC2RT_DIAG=1 over the same kernel objects (Makefile).  The product library reads no environment variable: a
@@ -84,19 +101,16 @@ struct c2rt_ctx {
     unsigned long long *counters = nullptr; /* [0..2]: RenderParams::ray_counters (reset per counted frame); [3]: RenderParams::redo_counter (cumulative) */
     c2rt_trace_result *probe = nullptr;
     uint8_t *srgb_lut = nullptr;   /* [4097] */
-    uint32_t *retry_list = nullptr; /* RenderParams::retry_list: [0] count, then tile (block) indices */
-    uint32_t *tile_masks = nullptr; /* RenderParams::tile_masks: 4 words per tile of the current frame's local rows */
-    size_t tile_mask_entries = 0;
+    FrameScratch scratch[kScratchSlots];
+    uint64_t scratch_tick = 0;
     uint32_t *tile_stats = nullptr; /* diagnostics (c2rt_debug_set_tile_stats): caller-owned device buffer */
-    size_t retry_words = 0;
     bool counters_valid = false;
-    /* Ordering of frames enqueued without a host sync (c2rt_render_frame_device): ev_inflight is recorded on the
-     * caller's stream behind everything the frame queued there; the next frame of this context — on whatever
-     * stream — waits for it ON THE DEVICE (hipStreamWaitEvent: the call itself does not block), the blocking entry
-     * points and the counter read-back wait for it on the host.  The library never keeps the caller's stream
-     * handle: the stream may be destroyed the moment the call returns (an event recorded on a destroyed stream
-     * completes with the stream's work).  has_inflight: ev_inflight has been recorded and not yet waited for by
-     * the host. */
+    /* The ray counters are the one per-frame resource shared by all streams: COUNTED frames (opts->count_rays, a
+     * test / diagnostics mode) enqueued without a host sync are ordered among themselves and against the counter
+     * read-back by ev_inflight, recorded on the caller's stream behind such a frame (the next counted frame waits
+     * for it on the device, the blocking entry points and c2rt_get_ray_stats on the host).  The library never
+     * keeps a caller's stream handle for use: the stream may be destroyed the moment the call returns.
+     * has_inflight: ev_inflight has been recorded and not yet waited for by the host. */
     hipEvent_t ev_inflight = nullptr;
     bool has_inflight = false;
 };
@@ -555,9 +569,31 @@ KernelVariant variant_of(const c2rt_ctx *ctx, const c2rt_camera_frame *cam)
     return v;
 }
 
+/* the scratch slot of `stream` (see FrameScratch); never fails: the least recently used slot is recycled after a
+ * device sync (whatever still reads its tables has finished then) */
+FrameScratch &scratch_for(c2rt_ctx *ctx, hipStream_t stream)
+{
+    const void *key = static_cast<const void *>(stream);
+    FrameScratch *pick = nullptr;
+    for (FrameScratch &f : ctx->scratch)
+        if (f.used && f.key == key) { pick = &f; break; }
+    if (!pick)
+        for (FrameScratch &f : ctx->scratch)
+            if (!f.used) { pick = &f; break; }
+    if (!pick) {
+        pick = &ctx->scratch[0];
+        for (FrameScratch &f : ctx->scratch)
+            if (f.tick < pick->tick) pick = &f;
+        (void)hipDeviceSynchronize();
+    }
+    pick->used = true;
+    pick->key = key;
+    pick->tick = ++ctx->scratch_tick;
+    return *pick;
+}
+
 /* The tiles' culling masks for the local rows [p.row_offset, p.row_offset + p.local_rows), by the pre-pass kernel,
- * in front of the frame kernel on the same stream (frames of one context are ordered across streams: one table
- * per context).  Sets p.tile_masks / mask_row0 / mask_rows; a no-op for frames without culling rectangles.
+ * in front of the frame kernel on the same stream (one table per stream of the context: FrameScratch).  Sets p.tile_masks / mask_row0 / mask_rows; a no-op for frames without culling rectangles.
  * Returns a hipError_t. */
 int prepare_tile_masks(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStream_t stream)
 {
@@ -566,14 +602,15 @@ int prepare_tile_masks(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, h
     p.mask_rows = p.local_rows;
     if (!p.n_cull || v.dof_or_stereo || !p.local_rows) return 0;
     const size_t entries = tile_mask_entries(p);
-    if (entries > ctx->tile_mask_entries) {
-        if (ctx->tile_masks) { (void)hipFree(ctx->tile_masks); ctx->tile_masks = nullptr; ctx->tile_mask_entries = 0; }
-        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->tile_masks), entries * 4 * sizeof(uint32_t));
+    FrameScratch &sc = scratch_for(ctx, stream);
+    if (entries > sc.tile_mask_entries) {
+        if (sc.tile_masks) { (void)hipFree(sc.tile_masks); sc.tile_masks = nullptr; sc.tile_mask_entries = 0; }
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&sc.tile_masks), entries * 4 * sizeof(uint32_t));
         if (e != hipSuccess) return (int)e;
-        ctx->tile_mask_entries = entries;
+        sc.tile_mask_entries = entries;
     }
-    p.tile_masks = ctx->tile_masks;
-    return launch_tile_masks(p, ctx->tile_masks, stream);
+    p.tile_masks = sc.tile_masks;
+    return launch_tile_masks(p, sc.tile_masks, stream);
 }
 
 /* One frame launch.  Scenes with nested CsgOps (depth >= 2) run the kernel with a reduced hit-stack
@@ -603,15 +640,16 @@ int launch_frame(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStre
     }
     if (levels < 2) return launch_render(p, v, stream);
     const size_t blocks = (size_t)p.blocks_x * ((p.tiles_y + 7u) / 8u * 8u);
-    if (blocks + 1 > ctx->retry_words) {
-        if (ctx->retry_list) { (void)hipFree(ctx->retry_list); ctx->retry_list = nullptr; ctx->retry_words = 0; }
-        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->retry_list), (blocks + 1) * sizeof(uint32_t));
+    FrameScratch &sc = scratch_for(ctx, stream);
+    if (blocks + 1 > sc.retry_words) {
+        if (sc.retry_list) { (void)hipFree(sc.retry_list); sc.retry_list = nullptr; sc.retry_words = 0; }
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&sc.retry_list), (blocks + 1) * sizeof(uint32_t));
         if (e != hipSuccess) return (int)e;
-        ctx->retry_words = blocks + 1;
+        sc.retry_words = blocks + 1;
     }
-    p.retry_list = ctx->retry_list;
+    p.retry_list = sc.retry_list;
     p.retry_max = (uint32_t)blocks;
-    hipError_t e = hipMemsetAsync(ctx->retry_list, 0, sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(sc.retry_list, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     int r = launch_render(p, v, stream);
     if (r != 0 || first_cap >= kCsgFullCap(levels)) return r;
@@ -755,9 +793,10 @@ void c2rt_destroy(c2rt_ctx *ctx)
     for (c2rt_ctx *p : ctx->peers) c2rt_destroy(p);
     ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize(); /* frames may still be in flight on callers' streams */
     if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
-    if (ctx->ev_inflight) { (void)hipEventSynchronize(ctx->ev_inflight); (void)hipEventDestroy(ctx->ev_inflight); }
+    if (ctx->ev_inflight) (void)hipEventDestroy(ctx->ev_inflight);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->copy_stream2) { (void)hipStreamSynchronize(ctx->copy_stream2); (void)hipStreamDestroy(ctx->copy_stream2); }
@@ -765,9 +804,13 @@ void c2rt_destroy(c2rt_ctx *ctx)
         if (e) (void)hipEventDestroy(e);
     for (const auto &pb : ctx->pinned) (void)hipHostUnregister(pb.first);
     void *bufs[] = {ctx->geoms, ctx->nodes, ctx->shaders, ctx->textures, ctx->lights, ctx->texels,
-                    ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut, ctx->shadow_rects, ctx->retry_list, ctx->tile_masks};
+                    ctx->frame, ctx->counters, ctx->probe, ctx->srgb_lut, ctx->shadow_rects};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (FrameScratch &f : ctx->scratch) {
+        if (f.tile_masks) (void)hipFree(f.tile_masks);
+        if (f.retry_list) (void)hipFree(f.retry_list);
+    }
     delete ctx;
 }
 
@@ -810,6 +853,8 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
 
     ctx->has_scene = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    /* frames enqueued on callers' streams may still be reading the tables about to be replaced */
+    HIP_TRY(ctx, hipDeviceSynchronize());
 
     /* geometries */
     std::vector<DevGeom> geoms(s->n_geoms);
@@ -831,6 +876,10 @@ static int upload_one(c2rt_ctx *ctx, const c2rt_scene_desc *s)
         } else if (t == C2RT_GEOM_SPHERE) {
             d.q[0] = d.p[3] * d.p[3];
         }
+        bool finite = true;
+        for (int i = 0; i < 4; ++i) finite = finite && std::isfinite(d.p[i]);
+        for (int i = 0; i < 6; ++i) finite = finite && std::isfinite(d.q[i]);
+        if (finite && !is_csg(t)) d.flags |= kGeomFinite;
     }
     std::vector<int> state(s->n_geoms, 0), memo(s->n_geoms, 0);
     std::vector<BoundInfo> bounds(s->n_geoms);
@@ -1165,8 +1214,8 @@ static int ensure_staging(c2rt_ctx *c, size_t bytes)
     return C2RT_OK;
 }
 
-/* the blocking entry points: nothing of an earlier stream-async frame of this context may still be in flight
- * (it would share the retry list and the counters), and nothing is in flight when they return */
+/* host wait for the last COUNTED stream-async frame (the ray counters are shared by all streams; everything else a
+ * frame writes is per stream, FrameScratch) */
 static int drain_inflight(c2rt_ctx *ctx)
 {
     if (!ctx->has_inflight) return C2RT_OK;
@@ -1180,7 +1229,8 @@ static int drain_inflight(c2rt_ctx *ctx)
 static int render_to_host(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_rgb,
                           uint32_t *out_rgb32, const volatile uint8_t *stop_flag)
 {
-    if (const int st = drain_inflight(ctx)) return st;
+    if (opts->count_rays)
+        if (const int st = drain_inflight(ctx)) return st;
     RenderParams p;
     fill_params(ctx, cam, opts, p);
     ctx->counters_valid = false;
@@ -1285,7 +1335,8 @@ constexpr uint32_t kMultiStrip = kTileH;
 static int render_to_host_multi(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_render_opts *opts, float *out_rgb,
                                 uint32_t *out_rgb32, const volatile uint8_t *stop_flag)
 {
-    if (const int st = drain_inflight(ctx)) return st;
+    if (opts->count_rays)
+        if (const int st = drain_inflight(ctx)) return st;
     const uint32_t G = 1u + (uint32_t)ctx->peers.size();
     const uint32_t sh = kMultiStrip, H = opts->height, W = opts->width;
     const uint32_t n_strips = (H + sh - 1) / sh, rem = H % sh; /* rem > 0: the last strip is partial */
@@ -1434,18 +1485,19 @@ int c2rt_render_frame_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const 
     if (!out_rgb_dev) return fail(ctx, C2RT_ERR_INVALID_ARG, "null output");
     if ((st = check_multi_opts(ctx, opts)) != C2RT_OK) return st;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    /* Frames of one context are ordered across streams (include/c2rt.h): the retry list, the mask table and the
-     * counters are per context, and two frames on two streams would race on them.  The order is made ON THE
-     * DEVICE — this stream waits for the event the previous frame left behind (a no-op within one stream) — so
-     * the call returns without waiting for that frame. */
+    /* Frames on one stream run in order; frames of this context on OTHER streams use other scratch slots
+     * (FrameScratch) and are independent of this one.  Only a counted frame shares something — the ray counters —
+     * and is ordered behind the previous counted frame on the device; the call never waits on the host. */
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if (ctx->has_inflight) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_inflight, 0));
+    if (opts->count_rays && ctx->has_inflight) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_inflight, 0));
     st = !ctx->peers.empty() ? render_device_multi(ctx, cam, opts, out_rgb_dev, stream)
                              : render_device(ctx, cam, opts, out_rgb_dev, stream);
-    /* also after a failed launch: whatever did get queued is ordered before the next frame */
-    const hipError_t rec = hipEventRecord(ctx->ev_inflight, stream);
-    if (rec == hipSuccess) ctx->has_inflight = true;
-    else if (st == C2RT_OK) st = fail(ctx, C2RT_ERR_HIP, "hipEventRecord(ev_inflight): %s", hipGetErrorString(rec));
+    if (opts->count_rays) {
+        /* also after a failed launch: whatever did get queued is ordered before the next counted frame */
+        const hipError_t rec = hipEventRecord(ctx->ev_inflight, stream);
+        if (rec == hipSuccess) ctx->has_inflight = true;
+        else if (st == C2RT_OK) st = fail(ctx, C2RT_ERR_HIP, "hipEventRecord(ev_inflight): %s", hipGetErrorString(rec));
+    }
     return st;
 }
 
@@ -1467,14 +1519,11 @@ int c2rt_render_frame(c2rt_ctx *ctx, const c2rt_camera_frame *cam, const c2rt_re
  * about to be unlocked */
 static int quiesce(c2rt_ctx *ctx)
 {
-    if (const int st = drain_inflight(ctx)) return st;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream2));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_inflight = false;
+    HIP_TRY(ctx, hipDeviceSynchronize()); /* the context's own streams and whatever callers' streams hold */
     for (c2rt_ctx *c : ctx->peers) {
         HIP_TRY(ctx, hipSetDevice(c->device));
-        HIP_TRY(ctx, hipStreamSynchronize(c->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(c->copy_stream));
+        HIP_TRY(ctx, hipDeviceSynchronize());
     }
     if (!ctx->peers.empty()) HIP_TRY(ctx, hipSetDevice(ctx->device));
     return C2RT_OK;

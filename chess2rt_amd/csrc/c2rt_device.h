@@ -56,6 +56,9 @@ enum GeomFlags : int32_t {
      *    a nested left child's hits carry a leaf != left and toggle inR). */
     kCsgShortA = 2,
     kCsgShortB = 4,
+    /* every parameter and table entry (p[], q[]) of a primitive is finite: the premise of the exact early-outs that
+     * reason about ordered comparisons (c2rt_trace.inc: cube_away) */
+    kGeomFinite = 8,
 };
 
 struct alignas(16) DevGeom {       /* 128 B */

@@ -14,7 +14,8 @@
  *   - CSG hit lists live in LDS, one per-lane stack per wave shared by the
  *     nesting levels ([entry][lane]: bank = lane, conflict-free for any per-lane
  *     entry index); only (dist, tag) is kept per hit and the winning hit is
- *     re-derived: 10 KiB per wave at depth 1, 20 KiB at depth 4;
+ *     re-derived: 16 entries = 10 KiB per wave at depth 1 and 2, 20 entries = 12.5 KiB at depth 3 and 4 on the
+ *     first pass (kCsgFirstCap, c2rt_device.h; 16 x depth on the rare full-capacity retry pass);
  *   - geometry is fp64 and colour fp32 in the reference's operation order
  *     (built with -ffp-contract=off), because checker edges, shadow
  *     terminators and CSG boundaries flip on 1-ulp differences.
@@ -62,7 +63,7 @@ __device__ __noinline__ UV c2_sphere_uv(double dx, double dz, double w)
 }
 /* Register budget per kernel instance, as waves per SIMD (512 VGPRs per lane and SIMD: 128 at 4 waves,
  * 168 at 3, 256 at 2).  With no hint hipcc takes all 512 registers and runs one wave per SIMD (1.8x
- * slower).  Chosen per instance from the compiler's resource remarks (profiles/r02_resource_usage.txt)
+ * slower).  Chosen per instance from the compiler's resource remarks (`make resource-usage`; profiles/r04_resource_usage.md)
  * so that NO instance spills VGPRs to scratch, except where a measurement says otherwise:
  *   depth 0 (no CSG), planes-only: 4 waves (111-127 VGPRs);
  *   depth 1, at most one light: 4 waves — 128 VGPRs since the cube / sphere face tables moved to the upload

@@ -22,8 +22,13 @@
  * Ranges (v_div_scale_f64 scales when the denominator is subnormal or above 2^1022, when the exponents
  * differ by >= 768, when the quotient would be subnormal, or when the numerator's exponent field is <= 53;
  * v_div_fixup steps in for zeros, infinities, NaNs and exponent differences beyond +-1024): with
- *     2^-120 <= |b| < 2^120     and     2^-900 <= |a| < 2^700
- * none of that applies.  The window tests are two 32-bit integer instructions on the high dword
+ *     2^-120 <= |b| < 2^120     and     2^-640 <= |a| < 2^640
+ * none of that applies (exponent difference <= 760 < 768, quotient >= 2^-760) and the equality holds by
+ * construction.  That covers everything the tracer divides: it admits numerators in [2^-240, 2^240) only
+ * (c2rt_trace.inc, Oob).  num_ok() below admits the wider 2^-900 <= |a| < 2^700 for the device check: out there
+ * v_div_scale does scale (by 2^+-128, exactly: a power of two) and v_div_fmas scales back, so the results still
+ * agree — by the sweep (tests/fp64_lean_check.hip: 0 mismatches in 5.5e11 operand pairs over that whole
+ * rectangle, profiles/r03_fp64_lean_sweep.json), not by the argument above.  The window tests are two 32-bit integer instructions on the high dword
  * (in_window: v_lshl_add_u32 + v_cmp_lt_u32; zero, subnormal, infinite and NaN operands fall outside any
  * window).  Callers branch wave-uniformly (`__all`) to the compiler's expansion when a lane is outside.
  *
@@ -54,7 +59,7 @@ LEAN_DEV bool in_window(double x)
 /* windows in which the sequences below are the compiler's expansions bit for bit (the tracer tests ONE
  * window, sqrt_ok's, for numerators and radicands alike: c2rt_trace.inc, Oob) */
 LEAN_DEV bool den_ok(double b) { return in_window<-120, 120>(b); }
-LEAN_DEV bool num_ok(double a) { return in_window<-900, 700>(a); }
+LEAN_DEV bool num_ok(double a) { return in_window<-900, 700>(a); } /* (wider than the by-construction window: header) */
 /* (the square of den_ok's window: a length taken from such an x can be divided by) */
 LEAN_DEV bool sqrt_ok(double x) { return in_window<-240, 240>(x); }
 

@@ -299,14 +299,17 @@ int c2rt_unpin_host_buffer(c2rt_ctx *ctx, float *out_rgb);
 /* Same, but the output stays in HBM: `out_rgb_dev` is a device pointer
  * (e.g. a torch tensor's data_ptr) and the kernels are enqueued on
  * `hip_stream` (a hipStream_t, NULL = default stream) without a host sync.
- * Frames of ONE context are ordered: per-frame scratch of the context (the
- * nested-CSG retry list, the tile-mask table, the ray counters) belongs to the
- * frame in flight, so a frame enqueued on a DIFFERENT stream than the
- * context's previous frame is ordered behind it ON THE DEVICE (an event the
- * previous frame left on its stream + hipStreamWaitEvent): the call returns at
- * once, but the two frames do not overlap — use one context per stream for
- * frames that should.  The library keeps no reference to `hip_stream`: the
- * caller may destroy it as soon as the call has returned. */
+ * Frames enqueued on one stream run in order, as everything on a HIP stream
+ * does.  Frames of ONE context on DIFFERENT streams are independent of each
+ * other and may overlap: the per-frame scratch a launch needs (the tile-mask
+ * table, the nested-CSG retry list) exists once per stream the context has
+ * rendered on (16 slots; a 17th stream recycles the least recently used one
+ * after a device sync), so the call neither waits for an earlier frame nor
+ * leaves an event in the queue.  The one shared resource is the ray counters:
+ * frames with opts->count_rays = 1 are ordered among themselves on the device.
+ * The library keeps no reference to `hip_stream` (the handle is only compared):
+ * the caller may destroy it as soon as the call has returned.  The caller owns
+ * the usual hazards of its buffers (two frames into one `out_rgb_dev`). */
 int c2rt_render_frame_device(c2rt_ctx *ctx, const c2rt_camera_frame *cam,
                              const c2rt_render_opts *opts, float *out_rgb_dev,
                              void *hip_stream);

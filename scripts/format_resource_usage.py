@@ -11,8 +11,8 @@ out = ["# Kernel resource usage as reported by the compiler (`make resource-usag
        "# DOF mode (0 none, 1 mono depth of field, 2 stereo), several lights, ray-counting instance>; render_kernel_dof<depth,",
        "# several lights, mode, counting>; render_kernel_planes<mode, counting> (scenes of axis planes only).  The production",
        "# instances are the `..., false>` ones; the counting instances (`..., true>`) run only when opts->count_rays is set.",
-       "# Dynamic LDS per wave: hit stack entries x 640 B (depth 1/2: 16, depth 3: 24, depth 4: 32 entries on the first pass;",
-       "# 16 x depth on the retry pass).  Since round 3 the production instances of depth <= 3 hold the trace TWICE (lean:: + the\n# exact:: redo, c2rt_trace.inc); the counting instances and depth 4 hold exact:: only.",
+       "# Dynamic LDS per wave: hit stack entries x 640 B (depth 1/2: 16, depth 3/4: 20 entries on the first pass — kCsgFirstCap,",
+       "# c2rt_device.h; 16 x depth on the retry pass).  Since round 3 the production instances of depth <= 3 hold the trace TWICE (lean:: + the\n# exact:: redo, c2rt_trace.inc); the counting instances and depth 4 hold exact:: only.",
        "",
        "| kernel | VGPRs | AGPRs | scratch B/lane | waves/SIMD | SGPRs spilled (to VGPR lanes) | VGPRs spilled |", "|---|---|---|---|---|---|---|"]
 for b in blocks:

@@ -1251,11 +1251,12 @@ def test_interactive_camera_sequence_matches_the_oracle(gpu_ctx):
     assert scene.camera.pos[1] != 165.0
 
 
-def test_frames_of_one_context_on_two_streams_are_ordered(gpu_ctx):
+def test_frames_of_one_context_on_two_streams(gpu_ctx):
     """c2rt_render_frame_device on two different streams of ONE context, back to back, for a nested-CSG scene
-    (its frames use the context's retry list): include/c2rt.h promises that the second frame is ordered behind
-    the first ON THE DEVICE (event + hipStreamWaitEvent), so both frames are complete and equal the frames
-    rendered alone — and the second call returns without waiting for the first frame."""
+    (its frames use a retry list and a tile-mask table): include/c2rt.h promises that frames on different streams
+    are independent — each stream has its own scratch slot in the context — so both frames are complete and equal
+    the frames rendered alone, whatever their overlap, and no call waits on the host for an earlier frame.  Counted
+    frames (shared ray counters) on two streams are ordered on the device and each reports its own counts."""
     import torch
 
     scene, cam_a, opts = load_config("csg_stress_320x240_t1")
@@ -1285,7 +1286,17 @@ def test_frames_of_one_context_on_two_streams_are_ordered(gpu_ctx):
     host = gpu_ctx.renderFrame(cam_a, opts)
     torch.cuda.synchronize(dev)
     assert np.array_equal(host, alone[0].cpu().numpy()) and torch.equal(b, alone[1])
-    # the ordering does not block the host: a long frame (2048x1536 x5 taps of the depth-4 scene, several ms) on
+    # counted frames on two streams: ordered among themselves (the counters are shared), frames and counts intact
+    _, _, copts = load_config("csg_stress_320x240_t1", count_rays=1)
+    gpu_ctx.renderFrame(cam_b, copts)
+    rays_b = gpu_ctx.rayStats()
+    for rep in range(3):
+        gpu_ctx.renderFrameDevice(cam_a, copts, a.data_ptr(), s1.cuda_stream)
+        gpu_ctx.renderFrameDevice(cam_b, copts, b.data_ptr(), s2.cuda_stream)
+        assert gpu_ctx.rayStats() == rays_b
+        torch.cuda.synchronize(dev)
+        assert torch.equal(a, alone[0]) and torch.equal(b, alone[1]), rep
+    # no call blocks the host: a long frame (2048x1536 x5 taps of the depth-4 scene, several ms) on
     # s1, then a frame on s2 — the second CALL is back while the first FRAME is still running
     big = scene.renderOpts(taps=c2.TAPS_REF5)
     scene.setFrameSize(2048, 1536)
@@ -1300,8 +1311,18 @@ def test_frames_of_one_context_on_two_streams_are_ordered(gpu_ctx):
     gpu_ctx.renderFrameDevice(cam_b, opts, b.data_ptr(), s2.cuda_stream)
     first_still_running = not done.query()
     torch.cuda.synchronize(dev)
-    assert first_still_running, "c2rt_render_frame_device waited on the host for the previous stream's frame"
+    assert first_still_running, "c2rt_render_frame_device waited on the host for another stream's frame"
     assert torch.equal(b, alone[1])
+    scene.setFrameSize(W, H)
+    small = opts
+    # more streams than scratch slots (16): the least recently used slot is recycled, frames unchanged
+    many = [torch.cuda.Stream(dev) for _ in range(19)]
+    outs = [torch.full((H, W, 3), -1.0, dtype=torch.float32, device=dev) for _ in many]
+    for i, st in enumerate(many):
+        gpu_ctx.renderFrameDevice(cam_a if i % 2 == 0 else cam_b, small, outs[i].data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize(dev)
+    for i in range(len(many)):
+        assert torch.equal(outs[i], alone[i % 2]), i
 
 
 def test_the_callers_stream_may_be_destroyed_after_the_call(gpu_ctx):
@@ -1329,7 +1350,7 @@ def test_the_callers_stream_may_be_destroyed_after_the_call(gpu_ctx):
             assert gpu_ctx.rayStats() == rays              # counters of the frame that ran on it
             st2 = C.c_void_p()
             assert hip.hipStreamCreate(C.byref(st2)) == 0
-            gpu_ctx.renderFrameDevice(cam, opts, dev.value, st2.value)     # orders itself behind the dead stream's event
+            gpu_ctx.renderFrameDevice(cam, opts, dev.value, st2.value)     # a counted frame: ordered behind the dead stream's event
             host = gpu_ctx.renderFrame(cam, opts)                          # blocking entry point drains first
             assert np.array_equal(host, want)
             got = np.empty_like(want)
