@@ -38,7 +38,7 @@ struct FrameScratch {
     const void *key = nullptr;
     bool used = false;
     uint64_t tick = 0;
-    uint32_t *tile_masks = nullptr; /* RenderParams::tile_masks: 4 words per tile of the frame's local rows */
+    uint32_t *tile_masks = nullptr; /* RenderParams::tile_masks: 4 words per tile of the frame's local rows, x 2 tables */
     size_t tile_mask_entries = 0;
     uint32_t *retry_list = nullptr; /* RenderParams::retry_list: [0] count, then tile (block) indices */
     size_t retry_words = 0;
@@ -605,16 +605,21 @@ int prepare_tile_masks(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, h
     FrameScratch &sc = scratch_for(ctx, stream);
     if (entries > sc.tile_mask_entries) {
         if (sc.tile_masks) { (void)hipFree(sc.tile_masks); sc.tile_masks = nullptr; sc.tile_mask_entries = 0; }
-        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&sc.tile_masks), entries * 4 * sizeof(uint32_t));
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&sc.tile_masks), entries * 8 * sizeof(uint32_t));
         if (e != hipSuccess) return (int)e;
         sc.tile_mask_entries = entries;
     }
     p.tile_masks = sc.tile_masks;
+    p.mask_entries = (uint32_t)entries;
     return launch_tile_masks(p, sc.tile_masks, stream);
 }
 
 /* One frame launch.  Scenes with nested CsgOps (depth >= 2) run the kernel with a reduced hit-stack
  * capacity (two waves per SIMD instead of one at depth 4) and then, on the same stream, the
+ * full-capacity relaunch over the tiles that overflowed it — none, for trees whose primitives yield
+ * their two hits (RenderParams::retry_list; c2rt_kernels.hip, csg_intersect).  Returns a hipError_t. */
+/* One frame launch.  Scenes with nested CsgOps (depth >= 2) run the kernel with a reduced hit-stack
+ * capacity (three waves per SIMD instead of one at depth 4) and then, on the same stream, the
  * full-capacity relaunch over the tiles that overflowed it — none, for trees whose primitives yield
  * their two hits (RenderParams::retry_list; c2rt_kernels.hip, csg_intersect).  Returns a hipError_t. */
 int launch_frame(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, hipStream_t stream)

@@ -219,12 +219,15 @@ struct RenderParams {
     uint32_t csg_cap;
     uint32_t retry_mode, retry_max;
     uint32_t *retry_list;
-    /* per tile: {primary mask, shadow mask of light 0, ground bits, 0} — written by the pre-pass kernel
+    /* per tile, 4 words: {primary mask, shadow mask of light 0, ground bits, 0}; frames with several culled lights
+     * carry a second table of the same layout behind it, mask_entries entries further on: {shadow masks of lights
+     * 1..3, 0} (c2rt_trace.inc: light_shadow_mask) — written by the pre-pass kernel
      * (launch_tile_masks, c2rt_trace.inc: tile_mask_entry) once per frame with n_cull != 0, read by the frame
      * kernel with one scalar load per tile.  The table covers the local rows [mask_row0, mask_row0 + mask_rows)
      * (mask_row0 a multiple of the tile height): the launches of a chunked host-output frame share one table */
     const uint32_t *tile_masks;
     uint32_t mask_row0, mask_rows;
+    uint32_t mask_entries;         /* entries of the (first) table: tile_mask_entries() */
     /* diagnostics build only (make VARIANT=tilestats EXTRA_HIPFLAGS=-DC2RT_TILE_STATS=1, scripts/tile_stats.py):
      * per tile {shader-clock cycles the wave spent on it, class bits}; never read by the product build */
     uint32_t *tile_stats;
@@ -261,7 +264,8 @@ template <> int launch_render_level<3>(const RenderParams &, bool, void *);
 template <> int launch_render_level<4>(const RenderParams &, bool, void *);
 int launch_render(const RenderParams &p, const KernelVariant &v, void *stream);
 int launch_probe(const RenderParams &p, const KernelVariant &v, void *stream);
-/* entries of RenderParams::tile_masks a launch of `p` reads (4 words each); the pre-pass that fills them */
+/* entries of RenderParams::tile_masks a launch of `p` reads (4 words each, twice that with several culled lights);
+ * the pre-pass that fills them */
 size_t tile_mask_entries(const RenderParams &p);
 int launch_tile_masks(const RenderParams &p, uint32_t *table, void *stream);
 int launch_deinterleave(const float *gathered, float *frame, uint32_t width, uint32_t height,

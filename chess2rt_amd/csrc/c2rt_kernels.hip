@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(kWave) probe_kernel(const RenderParams P)
     cx.lane_stats = nullptr;
 #endif
     cx.block = 0;
+    cx.mask_slot = 0;
     cx.primary_mask = 0xFFFFFFFFu;
     cx.shadow_mask0 = 0xFFFFFFFFu;
     cx.shadow_ground_only = false;
@@ -279,12 +280,15 @@ __global__ void __launch_bounds__(256) tile_masks_kernel(const RenderParams P, u
     const uint32_t cols = P.blocks_x * kWavesPerBlock;
     const uint32_t trow = i / cols, tcol = i % cols;
     if (trow >= tile_rows) return;
-    uint32_t m[4];
+    uint32_t m[8];
     exact::tile_mask_entry(P, (exact::KArgs)__builtin_amdgcn_kernarg_segment_ptr(), trow, tcol, m);
     typedef uint32_t __attribute__((ext_vector_type(4))) u4_t;
-    u4_t v;
+    u4_t v, w;
     v.x = m[0]; v.y = m[1]; v.z = m[2]; v.w = m[3];
-    reinterpret_cast<u4_t *>(table)[exact::tile_mask_slot(P, trow, tcol)] = v;
+    w.x = m[4]; w.y = m[5]; w.z = m[6]; w.w = m[7];
+    const size_t slot = exact::tile_mask_slot(P, trow, tcol);
+    reinterpret_cast<u4_t *>(table)[slot] = v;
+    if (P.n_cull_lights > 1u) reinterpret_cast<u4_t *>(table)[(size_t)P.mask_entries + slot] = w; /* lights 1..3 */
 }
 #endif /* C2RT_UNIT == 5 */
 

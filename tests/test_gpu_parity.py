@@ -599,6 +599,54 @@ def test_occluder_outside_the_left_childs_box(gpu_ctx, tmp_path, scenes_dir):
         assert gpu_ctx.rayStats() == (st["primary"], st["shadow"])
 
 
+def test_nested_csg_trees_that_only_shadow_the_view(gpu_ctx, tmp_path):
+    """The shadow masks of lights 1.. come from the per-tile table the pre-pass writes (c2rt_trace.inc:
+    light_shadow_mask; until round 4 every sample derived them with a ballot).  Here the deep trees (depth 3 and 4)
+    are OUT of view and only their shadows — from two lights on opposite sides, and from five lights, one more than
+    the table holds masks for — fall into the frame, next to a depth-1 and a depth-2 tree in view: a mask that culled
+    one of them for a tile its shadow crosses would lose that shadow.  Frames and ray counts equal the oracle's, at a
+    frame with clipped tiles too."""
+    geoms = """Plane "floor" { y 0 }
+        Cube "c1" { center 0 40 0; side 60 }
+        Sphere "s1" { center 0 40 0; R 38 }
+        CsgDiff "d1" { left "c1"; right "s1" }
+        Sphere "s2" { center 0 40 0; R 20 }
+        CsgUnion "u2" { left "s2"; right "d1" }
+        Cube "c3" { center 0 40 0; side 80 }
+        CsgInter "i3" { left "c3"; right "u2" }
+        Sphere "s4" { center 10 50 5; R 30 }
+        CsgDiff "d4" { left "i3"; right "s4" }
+        Cube "k1" { center 0 15 0; side 30 }
+        Sphere "k2" { center 0 15 0; R 19 }
+        CsgDiff "e1" { left "k1"; right "k2" }
+        Sphere "k3" { center 0 22 0; R 9 }
+        CsgUnion "e2" { left "e1"; right "k3" }"""
+    lights3 = """PointLight "a" { pos -600 500 -200; color 1 0.9 0.8; power 900000 }
+        PointLight "b" { pos 700 300 100; color 0.5 0.6 1; power 500000 }"""
+    lights5 = lights3 + """
+        PointLight "c" { pos 0 900 -900; color 0.3 0.3 0.3; power 900000 }
+        PointLight "d" { pos 100 400 900; color 0.2 0.4 0.2; power 900000 }
+        PointLight "e" { pos -900 200 900; color 0.4 0.2 0.2; power 900000 }"""
+    for name, lights, size in (("two_lights", lights3, (320, 240)), ("two_lights_clipped", lights3, (333, 217)), ("five_lights", lights5, (200, 152))):
+        text = """Scene { GlobalSettings { ambientLightColor 0.05 0.05 0.05; AAEnabled false }
+            Camera { pos 0 120 -260; pitch -22; fov 60 }
+            Lights { %s }
+            Geometries { %s }
+            Shaders {
+              Lambert "w" { color 0.9 0.9 0.9 }
+              Phong "g" { color 0.8 0.6 0.1; exponent 20 }
+            }
+            Nodes {
+              Node "floor" { geometry "floor"; shader "w" }
+              Node "deep_left"  { geometry "d4"; shader "g"; translate -330 0 60 }     // depth 4, left of the view
+              Node "deep_right" { geometry "i3"; shader "g"; translate 340 0 40 }      // depth 3, right of the view
+              Node "mid" { geometry "e2"; shader "g"; translate 60 0 -20 }             // depth 2, in view
+              Node "small" { geometry "e1"; shader "w"; translate -70 0 -40 }          // depth 1, in view
+            } }""" % (lights, geoms)
+        nne, _ = _check_scene_text(gpu_ctx, tmp_path / (name + ".sdl"), text, size=size)
+        assert nne == 0, name
+
+
 def test_pathological_scenes_terminate_and_match(gpu_ctx, tmp_path):
     """Inputs on which the reference itself never terminates (findAllIntersections loops for ever when
     `p + dir*1e-6 == p` or the hit is NaN) or degenerates (NaN camera, zero-size primitives): the device
