@@ -615,10 +615,6 @@ int prepare_tile_masks(c2rt_ctx *ctx, RenderParams &p, const KernelVariant &v, h
 }
 
 /* One frame launch.  Scenes with nested CsgOps (depth >= 2) run the kernel with a reduced hit-stack
- * capacity (two waves per SIMD instead of one at depth 4) and then, on the same stream, the
- * full-capacity relaunch over the tiles that overflowed it — none, for trees whose primitives yield
- * their two hits (RenderParams::retry_list; c2rt_kernels.hip, csg_intersect).  Returns a hipError_t. */
-/* One frame launch.  Scenes with nested CsgOps (depth >= 2) run the kernel with a reduced hit-stack
  * capacity (three waves per SIMD instead of one at depth 4) and then, on the same stream, the
  * full-capacity relaunch over the tiles that overflowed it — none, for trees whose primitives yield
  * their two hits (RenderParams::retry_list; c2rt_kernels.hip, csg_intersect).  Returns a hipError_t. */
