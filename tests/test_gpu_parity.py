@@ -1380,6 +1380,7 @@ def test_the_callers_stream_may_be_destroyed_after_the_call(gpu_ctx):
     hip = C.CDLL("libamdhip64.so")
     hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
     hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
     hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     hip.hipFree.argtypes = [C.c_void_p]
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -1394,7 +1395,8 @@ def test_the_callers_stream_may_be_destroyed_after_the_call(gpu_ctx):
             st = C.c_void_p()
             assert hip.hipStreamCreate(C.byref(st)) == 0
             gpu_ctx.renderFrameDevice(cam, opts, dev.value, st.value)
-            assert hip.hipStreamDestroy(st) == 0          # drains the stream's work, then the handle is gone
+            assert hip.hipStreamSynchronize(st) == 0       # (what a caller does before it lets go of a stream)
+            assert hip.hipStreamDestroy(st) == 0           # the handle is gone; the library must not touch it again
             assert gpu_ctx.rayStats() == rays              # counters of the frame that ran on it
             st2 = C.c_void_p()
             assert hip.hipStreamCreate(C.byref(st2)) == 0
@@ -1404,6 +1406,7 @@ def test_the_callers_stream_may_be_destroyed_after_the_call(gpu_ctx):
             got = np.empty_like(want)
             assert hip.hipMemcpy(got.ctypes.data, dev, want.nbytes, 2) == 0  # hipMemcpyDeviceToHost
             assert np.array_equal(got, want)
+            assert hip.hipStreamSynchronize(st2) == 0
             assert hip.hipStreamDestroy(st2) == 0
             pinned = np.zeros_like(want)
             gpu_ctx.pinHostBuffer(pinned)
