@@ -18,7 +18,7 @@ s = c2.parseSceneFromFile(os.path.join(SCENES, scene_file)); s.setFrameSize(w, h
 cam = s.beginFrame(); opts = s.renderOpts(taps=taps)
 ctx.uploadScene(s.desc)
 tx, ty = (w + 7) // 8, (h + 7) // 8
-stats = torch.zeros((ty * tx + 4 + 3 * 8, 2), dtype=torch.int32, device="cuda:0")   # + four 64-bit lane counters + 8 regions x {ticks, lanes, slots} at the end
+stats = torch.zeros((ty * tx + 4 + 3 * 9, 2), dtype=torch.int32, device="cuda:0")   # + four 64-bit lane counters + 9 regions x {ticks, lanes, slots} at the end
 lib = _abi.load_library()
 lib.c2rt_debug_set_tile_stats.argtypes = [C.c_void_p, C.c_void_p]; lib.c2rt_debug_set_tile_stats.restype = None
 lib.c2rt_debug_set_tile_stats(ctx.handle, C.c_void_p(stats.data_ptr()))
@@ -47,9 +47,9 @@ for n in range(min(nn, 24)):
 if lane[1]:
     print("  depth-1 CSG evaluations entered: %.1f of 64 lanes active on average (%.3f); child stepping calls: %.1f of 64 (%.3f)" % (
         64.0 * lane[0] / lane[1], lane[0] / lane[1], 64.0 * lane[2] / max(lane[3], 1), lane[2] / max(lane[3], 1)))
-reg = lane[4:4 + 24].reshape(8, 3).astype(np.float64)
+reg = lane[4:4 + 27].reshape(9, 3).astype(np.float64)
 names = ["primary node loop (whole)", "  CsgOp evaluation (primary + shadow rays)", "  replay of the winning hit (inside it)", "closest hit's surface (hit_surface waterfall)",
-         "shade (whole, incl. shadow ray)", "  shadow ray (test_visibility)", "  texture lookup", "  lit branch (cos terms, Phong pow)"]
+         "shade (whole, incl. shadow ray)", "  shadow ray (test_visibility)", "  texture lookup", "  lit branch (cos terms, Phong pow)", "  (inside the surface waterfall) Sphere u,v: atan2, asin, x87 emulation"]
 whole = float(cyc.sum()) * 3       # the per-tile stamps hold the last of the 3 frames; the region counters add up all 3
 if reg[:, 2].any():
     print("  regions (share of all wave-ticks; lanes active at entry, of 64; idle lane share x time share = what perfect regrouping of that region could win):")
