@@ -1377,7 +1377,10 @@ def test_the_callers_stream_may_be_destroyed_after_the_call(gpu_ctx):
     """The library keeps no reference to the caller's stream (round-3 advisor): render on a stream, destroy it,
     then every kind of call on the same context still works — blocking frames, the ray counters of the frame that
     ran on the destroyed stream, a frame on another stream, pin / unpin."""
-    hip = C.CDLL("libamdhip64.so")
+    # the HIP runtime libc2rt.so itself is bound to: symbols looked up through ITS handle resolve in its own dependency
+    # tree.  (C.CDLL("libamdhip64.so") can map a second copy of the runtime — torch bundles one — and a stream of one
+    # runtime handed to the other aborts inside HIP.)
+    hip = _abi.load_library()
     hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
     hip.hipStreamDestroy.argtypes = [C.c_void_p]
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
