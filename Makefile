@@ -13,7 +13,13 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -fhip-fp32-
 # stepping loops of a kernel that is already at its register budget: more values live across the loops,
 # more SGPRs spilled to VGPR lanes.  Measured with it off (profiles/r02_variants.md): lecture5 4K 1 tap
 # 0.389 -> 0.375 ms, zaphod DOF 5.23 -> 5.04 ms, depth-4 VGPR spills 90 -> 60.
-KERNELFLAGS := -mllvm -disable-machine-licm
+# -phi-node-folding-threshold=4 (round 4; LLVM's default is 2): SimplifyCFG turns slightly larger two-way branches into
+# selects.  The only one of ~25 code-generation options screened that helps (profiles/r04_variants.md step 8): the
+# headline instance drops from 122 to 118 VGPRs and from 151 to 135 SGPRs spilled to VGPR lanes; lecture5 4K x5
+# 1.016 -> 0.997 ms, 4K x1 0.255 -> 0.249, 8K x4 3.20 -> 3.14, 1080p 0.078 -> 0.077; planes-only and depth-4
+# instances unchanged.  (6 / 8 / 16: 133 spilled, a little slower than 4; 3: no change.)  Speculating a few more
+# side-effect-free fp64 operations does not change a bit of any frame (the suite is bit-identical either way).
+KERNELFLAGS := -mllvm -disable-machine-licm -mllvm -phi-node-folding-threshold=4
 CXXFLAGS   := -O2 -std=c++17 -fPIC $(FPFLAGS) -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 CSRC       := chess2rt_amd/csrc
 # development knob: `make VARIANT=name EXTRA_HIPFLAGS=... EXTRA_KERNEL_FLAGS=...` builds chess2rt_amd/libc2rt_name.so
@@ -35,7 +41,8 @@ all: $(LIBNAME) $(if $(VARIANT),,$(DIAGNAME)) oracle/libc2rt_oracle.so oracle/li
 $(BUILD):
 	mkdir -p $(BUILD)
 
-$(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_trace.inc $(CSRC)/c2rt_device.h $(CSRC)/x87.h $(CSRC)/fp64_lean.h include/c2rt.h | $(BUILD)
+# (the Makefile is a prerequisite: the arithmetic and code-generation flags are part of what a kernel object is)
+$(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_trace.inc $(CSRC)/c2rt_device.h $(CSRC)/x87.h $(CSRC)/fp64_lean.h include/c2rt.h Makefile | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$* -c $< -o $@
 
 $(BUILD)/c2rt_api.o: $(CSRC)/c2rt_api.cpp $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
