@@ -20,6 +20,17 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -fhip-fp32-
 # instances unchanged.  (6 / 8 / 16: 133 spilled, a little slower than 4; 3: no change.)  Speculating a few more
 # side-effect-free fp64 operations does not change a bit of any frame (the suite is bit-identical either way).
 KERNELFLAGS := -mllvm -disable-machine-licm -mllvm -phi-node-folding-threshold=4
+# Per unit (= CSG nesting depth of the frame-kernel instances in it), on top of KERNELFLAGS: GVN's partial-redundancy
+# elimination off and SimplifyCFG's bonus-instruction threshold at 4 for every depth but 1 (profiles/r04_variants.md
+# step 10, same-call A/B): planes-only / depth-0 instances -1.1 ... -2.5 % (zaphod DOF 3.947 -> 3.905 ms, zaphod x4
+# 0.483 -> 0.472, lecture4 1080p 134.4 -> 138.0 Gray/s), csg_stress cut to depth 2 / 3 / 4: 1.715 -> 1.664, 3.735 ->
+# 3.50, 8.29 -> 8.14 ms; the depth-1 instances (the headline) are 0.6 % SLOWER with them and keep the common flags.
+KERNELFLAGS_u0 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
+KERNELFLAGS_u1 :=
+KERNELFLAGS_u2 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
+KERNELFLAGS_u3 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
+KERNELFLAGS_u4 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
+KERNELFLAGS_u5 :=
 CXXFLAGS   := -O2 -std=c++17 -fPIC $(FPFLAGS) -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 CSRC       := chess2rt_amd/csrc
 # development knob: `make VARIANT=name EXTRA_HIPFLAGS=... EXTRA_KERNEL_FLAGS=...` builds chess2rt_amd/libc2rt_name.so
@@ -43,7 +54,7 @@ $(BUILD):
 
 # (the Makefile is a prerequisite: the arithmetic and code-generation flags are part of what a kernel object is)
 $(BUILD)/c2rt_kernels_u%.o: $(CSRC)/c2rt_kernels.hip $(CSRC)/c2rt_trace.inc $(CSRC)/c2rt_device.h $(CSRC)/x87.h $(CSRC)/fp64_lean.h include/c2rt.h Makefile | $(BUILD)
-	$(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$* -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) $(KERNELFLAGS_u$*) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$* -c $< -o $@
 
 $(BUILD)/c2rt_api.o: $(CSRC)/c2rt_api.cpp $(CSRC)/c2rt_device.h include/c2rt.h | $(BUILD)
 	g++ $(CXXFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
@@ -75,10 +86,8 @@ oracle/libc2rt_oracle_count.so: oracle/c2rt_oracle.c oracle/c2rt_oracle.h includ
 # the compiler's own per-kernel register / scratch / occupancy figures (committed as profiles/rNN_resource_usage.txt:
 # rocprofv3's VGPR_Count column is in allocation granules and does not show them)
 resource-usage: | $(BUILD)
-	@for u in $(UNITS); do \
-	  $(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$$u -Rpass-analysis=kernel-resource-usage \
-	    -c $(CSRC)/c2rt_kernels.hip -o $(BUILD)/ru_u$$u.o 2>&1 | grep -E "remark:" | sed -e 's/.*remark: [^ ]* *//' -e 's/ \[-Rpass-analysis=kernel-resource-usage\]//' ; \
-	done
+	@$(foreach u,$(UNITS),$(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) $(KERNELFLAGS_u$(u)) $(EXTRA_KERNEL_FLAGS) -DC2RT_UNIT=$(u) -Rpass-analysis=kernel-resource-usage \
+	    -c $(CSRC)/c2rt_kernels.hip -o $(BUILD)/ru_u$(u).o 2>&1 | grep -E "remark:" | sed -e 's/.*remark: [^ ]* *//' -e 's/ \[-Rpass-analysis=kernel-resource-usage\]//' ;)
 
 clean:
 	rm -rf build build_* chess2rt_amd/libc2rt*.so oracle/libc2rt_oracle.so oracle/libc2rt_oracle_count.so tests/fp64_lean_check

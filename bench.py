@@ -67,7 +67,8 @@ def kernel_source_hash():
     # the flag definitions of the Makefile (not its targets or comments)
     with open(os.path.join(ROOT, "Makefile")) as f:
         for line in f:
-            if line.split(":=")[0].strip() in ("FPFLAGS", "HIPFLAGS", "KERNELFLAGS", "ARCH") or line.startswith("              -W"):
+            name = line.split(":=")[0].strip()
+            if name in ("FPFLAGS", "HIPFLAGS", "KERNELFLAGS", "ARCH") or name.startswith("KERNELFLAGS_u") or line.startswith("              -W"):
                 h.update(line.encode())
     h.update(os.environ.get("C2RT_LIB_VARIANT", "").encode())
     return h.hexdigest()[:16]

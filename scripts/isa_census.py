@@ -22,7 +22,7 @@ TRACE = os.path.join(ROOT, "chess2rt_amd/csrc/c2rt_trace.inc")
 def make_flags():
     flags = {}
     for line in open(os.path.join(ROOT, "Makefile")):
-        m = re.match(r"^(FPFLAGS|KERNELFLAGS)\s*:=\s*(.*)$", line)
+        m = re.match(r"^(FPFLAGS|KERNELFLAGS|KERNELFLAGS_u\d)\s*:=\s*(.*)$", line)
         if m:
             flags[m.group(1)] = m.group(2).strip()
     return flags
@@ -97,7 +97,7 @@ def main():
     out = os.path.join(ROOT, "build", "isa", "u%sg.s" % unit)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags["FPFLAGS"].split() + \
-          ["-fhip-fp32-correctly-rounded-divide-sqrt"] + flags["KERNELFLAGS"].split() + \
+          ["-fhip-fp32-correctly-rounded-divide-sqrt"] + flags["KERNELFLAGS"].split() + flags.get("KERNELFLAGS_u%s" % unit, "").split() + \
           ["-DC2RT_UNIT=%s" % unit, "-gline-tables-only", "--offload-device-only", "-S", SRC, "-o", out, "-I" + os.path.join(ROOT, "include")]
     csrc = os.path.dirname(SRC)
     newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith(('.hip', '.inc', '.h')))
