@@ -382,6 +382,15 @@ def measure(torch, dist, pipe, steps, warmup, world, dev):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # settle: ~40 ms of untimed frames in front of the W warm-up steps.  A timed region that starts on a GPU just
+    # back from idle measures its clocks and queues coming up (20 one-millisecond frames read 1.5 % slow, 20 frames
+    # of 0.08 ms 8 % slow, against the >= 3 s `sustained` leg); W and K themselves stay exactly as asked.
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.04:
+        for _ in range(4):
+            pipe.step()
+        pipe.drain()
+        torch.cuda.synchronize(dev)
     for _ in range(warmup):
         pipe.step()
     pipe.drain()
@@ -783,6 +792,10 @@ def main():
             if name == args.workload:
                 continue
             o = run(name, min(args.steps, 20), min(args.warmup, 3))
+            if o["elapsed"] < 0.03:
+                # a 20-frame burst of sub-millisecond frames measures the launch pipeline filling and the final
+                # synchronise (~50-100 us together) more than the frames: time at least ~40 ms of them
+                o = run(name, min(800, max(o["steps"], int(0.04 * o["steps"] / max(o["elapsed"], 1e-6)))), min(args.warmup, 3))
             rays = o["primary"] + o["shadow"]
             others[name] = {
                 "workload": "%s %dx%d, %d tap(s)%s" % (o["scene_file"], o["width"], o["height"], o["taps"],
@@ -791,6 +804,7 @@ def main():
                 "ms_per_frame": o["elapsed"] / o["steps"] * 1e3,
                 "kernel_ms": o["kernel_ms"],
                 "rays_per_frame": rays,
+                "steps": o["steps"],
             }
             if o["pipelined"]:
                 others[name]["two_frames_in_flight"] = {"Mray_per_s": rays * o["steps"] / o["pipelined"] / 1e6,
