@@ -878,6 +878,7 @@ def main():
                 "frames_per_s": r["steps"] / r["elapsed"],
                 "kernel_ms_rank0": r["kernel_ms"],
                 "kernel_events": r["kernel_events"],
+                "settle": "~40 ms of untimed frames in front of the W warm-up steps of every measurement (GPU clocks and queues back from idle); W and K as asked",
                 "other_workloads": others,
             },
             "roofline": {
