@@ -385,12 +385,17 @@ def measure(torch, dist, pipe, steps, warmup, world, dev):
     # settle: ~40 ms of untimed frames in front of the W warm-up steps.  A timed region that starts on a GPU just
     # back from idle measures its clocks and queues coming up (20 one-millisecond frames read 1.5 % slow, 20 frames
     # of 0.08 ms 8 % slow, against the >= 3 s `sustained` leg); W and K themselves stay exactly as asked.
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.04:
-        for _ in range(4):
+    if world == 1:
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < 0.04:
+            for _ in range(4):
+                pipe.step()
+            pipe.drain()
+            torch.cuda.synchronize(dev)
+    else:
+        for _ in range(16):   # (every rank the same number of steps: a step holds a collective)
             pipe.step()
         pipe.drain()
-        torch.cuda.synchronize(dev)
     for _ in range(warmup):
         pipe.step()
     pipe.drain()
@@ -878,7 +883,7 @@ def main():
                 "frames_per_s": r["steps"] / r["elapsed"],
                 "kernel_ms_rank0": r["kernel_ms"],
                 "kernel_events": r["kernel_events"],
-                "settle": "~40 ms of untimed frames in front of the W warm-up steps of every measurement (GPU clocks and queues back from idle); W and K as asked",
+                "settle": "untimed frames in front of the W warm-up steps of every measurement (GPU clocks and queues back from idle): ~40 ms of them at N = 1, 16 frames at N > 1; W and K as asked",
                 "other_workloads": others,
             },
             "roofline": {
