@@ -127,6 +127,17 @@ typedef const RenderParams __attribute__((address_space(4))) *KArgs;
  * lanes — if a lane reported an operand outside a lean window (c2rt_trace.inc).  The instances launched when
  * rays are being counted (CNT; tests/conftest.py renders every counted frame with BOTH instances and insists
  * on the same bits) run exact:: only, so that suite compares the two. */
+/* 1: in the instances named below the cold half reads its arguments through a kernarg pointer the optimiser
+ * cannot see through, so that nothing but that pointer and the tile index stays live across the lean half on its
+ * behalf.  Without it values both halves use (kernel arguments, table pointers) are kept in SGPRs from the top
+ * of the kernel and the lean half spills around them: render_kernel_idn<1> holds 254 v_writelane / v_readlane in
+ * its lean half without, 191 with (lean:: compiled alone: 184); lecture5.sdl 4K at 1 sample per pixel 0.245 ->
+ * 0.239 ms, 1080p 72 -> 71 us, 4K x5 0.999 -> 0.996 ms.  Depth-of-field, plane-only and nested-CSG instances
+ * are allocated no better or worse with it (profiles/r04_variants.md, step 12) and keep the plain call. */
+#ifndef C2RT_REDO_OPAQUE
+#define C2RT_REDO_OPAQUE 1
+#endif
+
 template <int LEVELS, int DOF, bool MLC, int PO, bool CNT>
 DEV void render_one(const RenderParams &P, KArgs K, const uint32_t b)
 {
@@ -138,7 +149,14 @@ DEV void render_one(const RenderParams &P, KArgs K, const uint32_t b)
             if (!__ballot(redo)) return;
             if (threadIdx.x % kWave == 0) atomicAdd(P.redo_counter, 1ull); /* c2rt_get_exact_redos */
         }
-        exact::render_tile<LEVELS, DOF, MLC, PO, false>(P, (exact::KArgs)K, b);
+        if constexpr (C2RT_REDO_OPAQUE && LEVELS <= 1 && !DOF && PO != lean::kSpecPlanes) {
+            KArgs K2 = K;
+            uint32_t b2 = b;
+            asm volatile("" : "+s"(K2), "+s"(b2));
+            exact::render_tile<LEVELS, DOF, MLC, PO, false>(*(const RenderParams *)K2, (exact::KArgs)K2, b2);
+        } else {
+            exact::render_tile<LEVELS, DOF, MLC, PO, false>(P, (exact::KArgs)K, b);
+        }
     }
 }
 
