@@ -21,12 +21,15 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -fhip-fp32-
 # side-effect-free fp64 operations does not change a bit of any frame (the suite is bit-identical either way).
 KERNELFLAGS := -mllvm -disable-machine-licm -mllvm -phi-node-folding-threshold=4
 # Per unit (= CSG nesting depth of the frame-kernel instances in it), on top of KERNELFLAGS: GVN's partial-redundancy
-# elimination off and SimplifyCFG's bonus-instruction threshold at 4 for every depth but 1 (profiles/r04_variants.md
-# step 10, same-call A/B): planes-only / depth-0 instances -1.1 ... -2.5 % (zaphod DOF 3.947 -> 3.905 ms, zaphod x4
-# 0.483 -> 0.472, lecture4 1080p 134.4 -> 138.0 Gray/s), csg_stress cut to depth 2 / 3 / 4: 1.715 -> 1.664, 3.735 ->
-# 3.50, 8.29 -> 8.14 ms; the depth-1 instances (the headline) are 0.6 % SLOWER with them and keep the common flags.
+# elimination off and SimplifyCFG's bonus-instruction threshold at 4 (profiles/r04_variants.md step 10, same-call
+# A/B): planes-only / depth-0 instances -1.1 ... -2.5 % (zaphod DOF 3.947 -> 3.905 ms, zaphod x4 0.483 -> 0.472,
+# lecture4 1080p 134.4 -> 138.0 Gray/s), csg_stress cut to depth 2 / 3 / 4: 1.715 -> 1.664, 3.735 -> 3.50, 8.29 ->
+# 8.14 ms.  The depth-1 instances (the headline) were 0.6 % slower with them at the time and went without; measured
+# again after steps 12 - 17 had changed what those instances keep in registers they gain 1.9 % (0.925 -> 0.908 ms,
+# 1080p +2.5 %; the threshold alone: 1.6 %) and the other depths still want theirs (step 18).  Kept per unit: the
+# answer has changed once already.
 KERNELFLAGS_u0 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
-KERNELFLAGS_u1 :=
+KERNELFLAGS_u1 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
 KERNELFLAGS_u2 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
 KERNELFLAGS_u3 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
 KERNELFLAGS_u4 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
