@@ -27,12 +27,15 @@ KERNELFLAGS := -mllvm -disable-machine-licm -mllvm -phi-node-folding-threshold=4
 # 8.14 ms.  The depth-1 instances (the headline) were 0.6 % slower with them at the time and went without; measured
 # again after steps 12 - 17 had changed what those instances keep in registers they gain 1.9 % (0.925 -> 0.908 ms,
 # 1080p +2.5 %; the threshold alone: 1.6 %) and the other depths still want theirs (step 18).  Kept per unit: the
-# answer has changed once already.
+# answer has changed once already.  Depth 4 also takes the scheduler's max-memory-clause strategy: those instances are
+# latency-bound (VALU busy 0.64, 43 % of the wave-cycles waiting for memory) and gain 2.3 % from it (csg_stress 7.80 ->
+# 7.62 ms; the other strategies 1.2 %); depth 3 LOSES 2.2 % with it, depth 2 and the issue-bound depths 0 / 1 do not
+# care (step 20).
 KERNELFLAGS_u0 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
 KERNELFLAGS_u1 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
 KERNELFLAGS_u2 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
 KERNELFLAGS_u3 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
-KERNELFLAGS_u4 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
+KERNELFLAGS_u4 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4 -mllvm -amdgpu-sched-strategy=max-memory-clause
 KERNELFLAGS_u5 :=
 CXXFLAGS   := -O2 -std=c++17 -fPIC $(FPFLAGS) -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 CSRC       := chess2rt_amd/csrc
