@@ -30,9 +30,9 @@ KERNELFLAGS := -mllvm -disable-machine-licm -mllvm -phi-node-folding-threshold=4
 # answer has changed once already.  Depth 4 also takes the scheduler's max-memory-clause strategy: those instances are
 # latency-bound (VALU busy 0.64, 43 % of the wave-cycles waiting for memory) and gain 2.3 % from it (csg_stress 7.80 ->
 # 7.62 ms; the other strategies 1.2 %); depth 3 LOSES 2.2 % with it, depth 2 and the issue-bound depths 0 / 1 do not
-# care (step 20).
+# care for it (step 20); depth 1 takes iterative-ilp, worth 0.6 % on the headline frame, and depth 0 keeps the default.
 KERNELFLAGS_u0 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
-KERNELFLAGS_u1 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
+KERNELFLAGS_u1 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4 -mllvm -amdgpu-sched-strategy=iterative-ilp
 KERNELFLAGS_u2 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
 KERNELFLAGS_u3 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
 KERNELFLAGS_u4 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4 -mllvm -amdgpu-sched-strategy=max-memory-clause
