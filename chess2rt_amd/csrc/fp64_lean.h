@@ -30,7 +30,9 @@
  * agree — by the sweep (tests/fp64_lean_check.hip: 0 mismatches in 5.5e11 operand pairs over that whole
  * rectangle, profiles/r03_fp64_lean_sweep.json), not by the argument above.  The window tests are two 32-bit integer instructions on the high dword
  * (in_window: v_lshl_add_u32 + v_cmp_lt_u32; zero, subnormal, infinite and NaN operands fall outside any
- * window).  Callers branch wave-uniformly (`__all`) to the compiler's expansion when a lane is outside.
+ * window).  Callers branch wave-uniformly (`__all`) to the compiler's expansion when a lane is outside —
+ * tests/fp64_lean_check.hip and near_one's callers; the tracer itself folds one window into an accumulator and
+ * redoes the tile instead (c2rt_trace.inc: Oob).
  *
  * sqrt_lean / inv_len: the compiler's own rsq + Goldschmidt sequence minus the 2^-767 scale test, the two
  * ldexp and the zero / infinity select — identical bits for 2^-700 <= x < 2^700 (sqrt_ok accepts 2^+-240).  inv_len also returns
