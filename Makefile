@@ -31,9 +31,9 @@ KERNELFLAGS := -mllvm -disable-machine-licm -mllvm -phi-node-folding-threshold=4
 # latency-bound (VALU busy 0.64, 43 % of the wave-cycles waiting for memory) and gain 2.3 % from it (csg_stress 7.80 ->
 # 7.62 ms; the other strategies 1.2 %); depth 3 LOSES 2.2 % with it, depth 2 and the issue-bound depths 0 / 1 do not
 # care for it (step 20); depth 1 takes iterative-ilp, worth 0.6 % on the headline frame; depth 2 iterative-ilp as well (-3 % on csg_stress cut
-# to depth 2), depth 0 max-ilp (lecture4 1080p +1.8 %, zaphod x4 -0.5 %), depth 3 the default (every other strategy is
-# slower there).
-KERNELFLAGS_u0 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4 -mllvm -amdgpu-sched-strategy=max-ilp
+# to depth 2); depth 0 and depth 3 keep the default (depth 0: max-ilp gains 1.8 % on lecture4 1080p but puts 32 B of
+# scratch into the depth-of-field planes instance; depth 3: every other strategy is slower).
+KERNELFLAGS_u0 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
 KERNELFLAGS_u1 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4 -mllvm -amdgpu-sched-strategy=iterative-ilp
 KERNELFLAGS_u2 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4 -mllvm -amdgpu-sched-strategy=iterative-ilp
 KERNELFLAGS_u3 := -mllvm -enable-pre=false -mllvm -bonus-inst-threshold=4
